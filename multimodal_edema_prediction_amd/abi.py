@@ -1,0 +1,116 @@
+"""ctypes binding of the C ABI declared in include/medp_hip.h (libmedp_hip.so, built in-tree by build.py).
+
+The product path has NO fallback: if the library is missing or a tensor is not on the GPU the call raises.
+Error mapping: rc < 0 (invalid argument) -> ValueError, rc > 0 (hipError_t) -> RuntimeError.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_uint, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmedp_hip.so")
+
+P, I, F, U, LL, SZ = c_void_p, c_int, c_float, c_uint, c_longlong, c_size_t
+
+
+class MedpVitLayer(ctypes.Structure):
+    _fields_ = [(n, P) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1", "ln2_w", "ln2_b",
+                                 "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2")]
+
+
+class MedpVitWeights(ctypes.Structure):
+    _fields_ = ([(n, I) for n in ("hidden", "n_layers", "n_heads", "mlp_hidden", "patch", "pos_side", "patch_kpad")]
+                + [("ln_eps", F)]
+                + [(n, P) for n in ("patch_w", "patch_b", "cls", "pos", "final_ln_w", "final_ln_b")]
+                + [("layers", ctypes.POINTER(MedpVitLayer))])
+
+
+class MedpEncoderWeights(ctypes.Structure):
+    """One x_transformers-style encoder (depth 1): see include/medp_hip.h"""
+    _fields_ = [(n, P) for n in ("g_attn", "qkv_w", "out_w", "g_ff", "ff1_w", "ff1_b", "ff2_w", "ff2_b", "g_final")]
+
+
+class MedpDuettWeights(ctypes.Structure):
+    _fields_ = ([(n, I) for n in ("n_vars", "n_static", "d_embedding", "n_heads", "n_layers", "d_ff", "d_hidden_embed",
+                                  "d_hidden_tab", "d_hidden_time", "n_obs_rows", "final_norm")]
+                + [("norm_eps", F)]
+                + [(n, P) for n in ("emb_w0", "emb_b0", "emb_bn_scale", "emb_bn_shift", "emb_w4", "emb_b4", "n_obs_table",
+                                    "tab_w0", "tab_b0", "tab_bn_scale", "tab_bn_shift", "tab_w4", "tab_b4", "special",
+                                    "time_w0", "time_b0", "time_bn_scale", "time_bn_shift", "time_w3", "time_b3",
+                                    "rep_embedding", "event_embedding")]
+                + [("event_enc", ctypes.POINTER(MedpEncoderWeights)), ("time_enc", ctypes.POINTER(MedpEncoderWeights))])
+
+
+# name -> (restype, argtypes); must list every function declared in include/medp_hip.h (tests/test_abi.py checks)
+SIGNATURES = {
+    "medp_last_error": (c_char_p, []),
+    "medp_version": (I, []),
+    "medp_arch": (c_char_p, []),
+    "medp_gemm_bf16_nt": (I, [P, P, P, I, I, I, I, I, I, P, P, P, I, I, I, P]),
+    "medp_attn_fwd_dh64": (I, [P, P, P, P, I, I, I, I, I, I, I, F, P]),
+    "medp_attn_small_fwd": (I, [P, I, LL, P, P, I, LL, P, I, I, P, I, I, I, I, I, F, F, U, U, P]),
+    "medp_attn_small_bwd": (I, [P, I, P, I, LL, P, P, I, LL, P, I, P, I, P, I, I, I, I, I, I, F, F, U, U, P]),
+    "medp_layernorm_fwd": (I, [P, I, P, P, P, I, I, P, P, I, I, F, P]),
+    "medp_colsum_workspace_bytes": (SZ, [I, I]),
+    "medp_layernorm_bwd": (I, [P, I, P, I, P, P, P, P, I, I, P, P, P, I, I, P]),
+    "medp_colsum_f32": (I, [P, I, P, P, I, I, P]),
+    "medp_scalenorm_fwd": (I, [P, I, P, P, I, I, P, I, I, F, P]),
+    "medp_scalenorm_bwd": (I, [P, I, P, I, P, P, P, I, I, P, P, I, I, P]),
+    "medp_cast_f32_bf16": (I, [P, I, P, I, I, I, P]),
+    "medp_transpose_to_bf16": (I, [P, I, I, P, I, I, I, P]),
+    "medp_gelu_bwd": (I, [P, P, P, LL, P]),
+    "medp_im2col_patch": (I, [P, P, I, I, I, I, I, I, P]),
+    "medp_vit_assemble": (I, [P, P, P, P, I, I, I, P]),
+    "medp_pos_embed_bicubic": (I, [P, P, I, I, I, I, P]),
+    "medp_vit_workspace_bytes": (SZ, [ctypes.POINTER(MedpVitWeights), I, I, I]),
+    "medp_vit_forward": (I, [ctypes.POINTER(MedpVitWeights), P, I, I, I, P, P, P, SZ, P]),
+}
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load libmedp_hip.so; raise (never fall back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"HIP extension {LIB_PATH} is missing: build it with `python -m multimodal_edema_prediction_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the hot path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc == 0:
+        return
+    msg = lib().medp_last_error().decode("utf-8", "replace")
+    if rc < 0:
+        raise ValueError(f"{what}: {msg}" if what else msg)
+    raise RuntimeError(f"{what}: HIP error {rc}: {msg}")
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: torch.Tensor | None) -> int | None:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libmedp_hip operates on GPU memory only (tensor is on %s); there is no CPU fallback" % t.device)
+    return t.data_ptr()
+
+
+def require_gpu() -> None:
+    lib()
+    if not torch.cuda.is_available():
+        raise RuntimeError("no HIP device is visible: the MI355X hot path cannot run (there is no CPU fallback)")

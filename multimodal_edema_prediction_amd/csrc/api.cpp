@@ -1,0 +1,18 @@
+// Library-level entry points of libmedp_hip: version / arch probe and the thread-local error string.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "medp_hip.h"
+
+static thread_local char g_err[512] = "";
+
+void medp_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* medp_last_error(void) { return g_err; }
+extern "C" int medp_version(void) { return 1; }
+extern "C" const char* medp_arch(void) { return "gfx950"; }

@@ -1,0 +1,79 @@
+// Shared device/host helpers for libmedp_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef uint16_t bf16_t;                                            // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;           // 8 bf16 = one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define MEDP_WAVE 64
+
+// ---- error plumbing (C ABI: 0 ok, <0 invalid argument, >0 hipError_t) --------------------------
+void medp_set_error(const char* fmt, ...);
+#define MEDP_CHECK_ARG(cond, ...)            \
+    do {                                     \
+        if (!(cond)) {                       \
+            medp_set_error(__VA_ARGS__);     \
+            return -1;                       \
+        }                                    \
+    } while (0)
+#define MEDP_LAUNCH_CHECK(name)                                                         \
+    do {                                                                                \
+        hipError_t e__ = hipGetLastError();                                             \
+        if (e__ != hipSuccess) {                                                        \
+            medp_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));      \
+            return (int)e__;                                                            \
+        }                                                                               \
+    } while (0)
+#define MEDP_TRY(expr)               \
+    do {                             \
+        int rc__ = (expr);           \
+        if (rc__ != 0) return rc__;  \
+    } while (0)
+
+// ---- bf16 <-> f32 --------------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// round-to-nearest-even; the plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN a NaN
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// ---- wave reductions (64 lanes) --------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// counter-based RNG for dropout: one 32-bit hash per (seed, stream, element) — regenerated in backward
+__device__ __forceinline__ uint32_t medp_hash(uint32_t seed, uint32_t stream, uint32_t idx) {
+    uint32_t x = idx * 0x9E3779B1u ^ (seed + 0x7F4A7C15u * (stream + 1u));
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    x += seed * 0x27D4EB2Fu; x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12;
+    return x;
+}
+// keep-mask: returns scale 1/(1-p) if kept, 0 if dropped
+__device__ __forceinline__ float dropout_scale(uint32_t seed, uint32_t stream, uint32_t idx, float p, float inv_keep) {
+    const uint32_t h = medp_hash(seed, stream, idx);
+    return ((float)(h >> 8) * (1.0f / 16777216.0f)) >= p ? inv_keep : 0.0f;
+}

@@ -1,0 +1,175 @@
+// Layout / cast / pointwise kernels (gfx950).  All HBM-bound: 16-B vector accesses, grid-stride, >= 2048 blocks.
+#include "common.h"
+#include "medp_hip.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy,
+                                                            int rows, int cols) {
+    const int c4 = cols >> 2;
+    const size_t total = (size_t)rows * c4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / c4), c = (int)(i % c4) * 4;
+        const float4 v = *(const float4*)(x + (size_t)r * ldx + c);
+        uint2 o;
+        o.x = pack_bf2(v.x, v.y);
+        o.y = pack_bf2(v.z, v.w);
+        *(uint2*)(y + (size_t)r * ldy + c) = o;
+    }
+}
+
+// y[c][r] = (bf16) x[r][c]   — 64x64 tiles through LDS (+1 pad), coalesced on both sides
+template <typename TIN>
+__global__ __launch_bounds__(256) void transpose_to_bf16_kernel(const TIN* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy,
+                                                                int rows, int cols) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        float v = 0.f;
+        if (r < rows && c < cols) {
+            if constexpr (sizeof(TIN) == 2) v = bf2f(((const bf16_t*)x)[(size_t)r * ldx + c]);
+            else v = ((const float*)x)[(size_t)r * ldx + c];
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows) y[(size_t)c * ldy + r] = f2bf(tile[tx][i]);
+    }
+}
+
+// out = dy * gelu'(pre)     (pre-activation saved in fp32 or bf16)
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ dx,
+                                                       size_t n) {
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+        const float4 g = *(const float4*)(dy + i), p = *(const float4*)(pre + i);
+        *(float4*)(dx + i) = make_float4(g.x * gelu_erf_grad(p.x), g.y * gelu_erf_grad(p.y), g.z * gelu_erf_grad(p.z),
+                                         g.w * gelu_erf_grad(p.w));
+    }
+}
+
+// ---- ViT front end ---------------------------------------------------------------------------------------
+// im2col for the 14x14 / stride-14 patch embedding: A[b*P + py*gw + px][c*196 + i*14 + j] = pix[b][c][py*14+i][px*14+j]
+// written as bf16 with the row padded to `kpad` (zeros) so the GEMM sees 16-B aligned rows.
+__global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restrict__ pix, bf16_t* __restrict__ A, int B, int C, int H,
+                                                           int W, int ps, int kpad) {
+    const int gh = H / ps, gw = W / ps, K = C * ps * ps;
+    const size_t total = (size_t)B * gh * gw * kpad;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int kk = (int)(i % kpad);
+        const size_t row = i / kpad;
+        float v = 0.f;
+        if (kk < K) {
+            const int c = kk / (ps * ps), rem = kk % (ps * ps), ii = rem / ps, jj = rem % ps;
+            const int px = (int)(row % gw), py = (int)((row / gw) % gh), b = (int)(row / ((size_t)gw * gh));
+            v = pix[(((size_t)b * C + c) * H + py * ps + ii) * W + px * ps + jj];
+        }
+        A[i] = f2bf(v);
+    }
+}
+
+// x[b][0][:] = cls + pos[0] ;  x[b][1+p][:] = patch[b*P+p][:] + pos[1+p]
+__global__ __launch_bounds__(256) void vit_assemble_kernel(const float* __restrict__ patch, const float* __restrict__ cls,
+                                                           const float* __restrict__ pos, float* __restrict__ x, int B, int P, int D) {
+    const int d4 = D >> 2;
+    const size_t total = (size_t)B * (P + 1) * d4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % d4) * 4;
+        const size_t tokrow = i / d4;
+        const int t = (int)(tokrow % (P + 1)), b = (int)(tokrow / (P + 1));
+        const float4 pe = *(const float4*)(pos + (size_t)t * D + c);
+        const float4 v = (t == 0) ? *(const float4*)(cls + c) : *(const float4*)(patch + ((size_t)b * P + t - 1) * D + c);
+        *(float4*)(x + tokrow * D + c) = make_float4(v.x + pe.x, v.y + pe.y, v.z + pe.z, v.w + pe.w);
+    }
+}
+
+// bicubic (A = -0.75, align_corners = False, no antialias) resize of the [s,s,D] position grid to [gh,gw,D];
+// token 0 (class position) is copied.  Matches torch.nn.functional.interpolate(mode="bicubic").
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+__global__ __launch_bounds__(256) void pos_bicubic_kernel(const float* __restrict__ pos, float* __restrict__ out, int s, int gh, int gw,
+                                                          int D) {
+    const size_t total = (size_t)(gh * gw + 1) * D;
+    const float A = -0.75f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int d = (int)(i % D), t = (int)(i / D);
+        if (t == 0) { out[i] = pos[d]; continue; }
+        const int oy = (t - 1) / gw, ox = (t - 1) % gw;
+        const float sy = (float)s / (float)gh, sx = (float)s / (float)gw;
+        const float fy = (oy + 0.5f) * sy - 0.5f, fx = (ox + 0.5f) * sx - 0.5f;
+        const int iy = (int)floorf(fy), ix = (int)floorf(fx);
+        const float ty = fy - iy, tx = fx - ix;
+        const float wy[4] = {cubic2(ty + 1.f, A), cubic1(ty, A), cubic1(1.f - ty, A), cubic2(2.f - ty, A)};
+        const float wx[4] = {cubic2(tx + 1.f, A), cubic1(tx, A), cubic1(1.f - tx, A), cubic2(2.f - tx, A)};
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int yy = min(max(iy - 1 + a, 0), s - 1);
+            float rowacc = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int xx = min(max(ix - 1 + c, 0), s - 1);
+                rowacc += wx[c] * pos[(size_t)(1 + yy * s + xx) * D + d];
+            }
+            acc += wy[a] * rowacc;
+        }
+        out[i] = acc;
+    }
+}
+
+inline int grid_for(size_t work_items) { return (int)min((size_t)4096, max((size_t)1, (work_items + 255) / 256)); }
+
+}  // namespace
+
+extern "C" int medp_cast_f32_bf16(const float* x, int ldx, void* y, int ldy, int rows, int cols, void* stream) {
+    MEDP_CHECK_ARG(x && y && rows > 0 && cols > 0, "cast: bad argument");
+    MEDP_CHECK_ARG(cols % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "cast: cols, ldx, ldy must be multiples of 4");
+    cast_f32_bf16_kernel<<<grid_for((size_t)rows * cols / 4), 256, 0, (hipStream_t)stream>>>(x, ldx, (bf16_t*)y, ldy, rows, cols);
+    MEDP_LAUNCH_CHECK("medp_cast_f32_bf16");
+    return 0;
+}
+
+extern "C" int medp_transpose_to_bf16(const void* x, int x_is_bf16, int ldx, void* y, int ldy, int rows, int cols, void* stream) {
+    MEDP_CHECK_ARG(x && y && rows > 0 && cols > 0 && ldx >= cols && ldy >= rows, "transpose: bad argument");
+    dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+    if (x_is_bf16)
+        transpose_to_bf16_kernel<bf16_t><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, ldx, (bf16_t*)y, ldy, rows, cols);
+    else
+        transpose_to_bf16_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)x, ldx, (bf16_t*)y, ldy, rows, cols);
+    MEDP_LAUNCH_CHECK("medp_transpose_to_bf16");
+    return 0;
+}
+
+extern "C" int medp_gelu_bwd(const float* dy, const float* pre, float* dx, long long n, void* stream) {
+    MEDP_CHECK_ARG(dy && pre && dx && n > 0 && n % 4 == 0, "gelu_bwd: bad argument (n must be a multiple of 4)");
+    gelu_bwd_kernel<<<grid_for((size_t)n / 4), 256, 0, (hipStream_t)stream>>>(dy, pre, dx, (size_t)n);
+    MEDP_LAUNCH_CHECK("medp_gelu_bwd");
+    return 0;
+}
+
+extern "C" int medp_im2col_patch(const float* pix, void* A, int B, int C, int H, int W, int patch, int kpad, void* stream) {
+    MEDP_CHECK_ARG(pix && A && B > 0 && C > 0 && patch > 0, "im2col: bad argument");
+    MEDP_CHECK_ARG(H % patch == 0 && W % patch == 0, "im2col: image %dx%d is not a multiple of the patch size %d", H, W, patch);
+    MEDP_CHECK_ARG(kpad >= C * patch * patch && kpad % 8 == 0, "im2col: kpad must be >= C*p*p and a multiple of 8");
+    const size_t total = (size_t)B * (H / patch) * (W / patch) * kpad;
+    im2col_patch_kernel<<<grid_for(total), 256, 0, (hipStream_t)stream>>>(pix, (bf16_t*)A, B, C, H, W, patch, kpad);
+    MEDP_LAUNCH_CHECK("medp_im2col_patch");
+    return 0;
+}
+
+extern "C" int medp_vit_assemble(const float* patch, const float* cls, const float* pos, float* x, int B, int P, int D, void* stream) {
+    MEDP_CHECK_ARG(patch && cls && pos && x && B > 0 && P > 0 && D % 4 == 0, "vit_assemble: bad argument");
+    vit_assemble_kernel<<<grid_for((size_t)B * (P + 1) * D / 4), 256, 0, (hipStream_t)stream>>>(patch, cls, pos, x, B, P, D);
+    MEDP_LAUNCH_CHECK("medp_vit_assemble");
+    return 0;
+}
+
+extern "C" int medp_pos_embed_bicubic(const float* pos, float* out, int src_side, int gh, int gw, int D, void* stream) {
+    MEDP_CHECK_ARG(pos && out && src_side > 0 && gh > 0 && gw > 0 && D > 0, "pos_embed_bicubic: bad argument");
+    pos_bicubic_kernel<<<grid_for((size_t)(gh * gw + 1) * D), 256, 0, (hipStream_t)stream>>>(pos, out, src_side, gh, gw, D);
+    MEDP_LAUNCH_CHECK("medp_pos_embed_bicubic");
+    return 0;
+}

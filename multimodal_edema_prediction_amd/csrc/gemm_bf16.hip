@@ -1,0 +1,193 @@
+// bf16 MFMA GEMM for gfx950:  C[M,N] = epilogue( A[M,K] · W[N,K]^T )
+//
+// Both operands are K-contiguous (torch `nn.Linear` layout), which is the natural operand layout
+// of v_mfma_f32_16x16x32_bf16: a lane's fragment is 8 consecutive k of one row (16 B).
+//
+// Structure (one 256-thread workgroup = 4 waves in 2x2, tile BM x BN x 64):
+//   * global -> LDS by LDS-DMA (`global_load_lds_dwordx4`, 16 B per lane, no VGPR round trip),
+//     double-buffered: the loads of K-tile t+1 are in flight while tile t is multiplied.
+//   * LDS rows are 128 B (64 bf16); the 16-B chunk index is XOR-swizzled with (row & 7) so that the
+//     ds_read_b128 fragment reads of 16 different rows are bank-conflict free.  LDS-DMA writes LDS
+//     linearly (wave base + lane*16), so the swizzle is applied to the per-lane SOURCE address and
+//     again on the read (both-sides-or-neither).
+//   * MFMA operand roles are swapped (A-operand := W rows, B-operand := activation rows) so each
+//     lane ends up with 4 consecutive output columns of one output row -> 16-B vector epilogue.
+//   * Ragged M / N / K: out-of-range 16-B chunks are sourced from a zero buffer (the LDS-DMA source
+//     address is per lane), so no padding convention is imposed on callers (K % 8 == 0 only).
+//   * Fused epilogue: + bias[n] -> GELU(erf) -> * scale[n] (LayerScale) -> + residual[m,n] -> fp32 or bf16.
+//   * blockIdx -> tile map is XCD-aware (bijective): the 8 XCDs each get a contiguous run of tiles that
+//     walks N fastest, so one XCD's L2 sees one A row-panel and the whole W.
+#include "common.h"
+#include "medp_hip.h"
+
+namespace {
+
+__device__ __attribute__((aligned(16))) uint32_t g_zero16[4] = {0, 0, 0, 0};
+
+struct GemmParams {
+    const bf16_t* A;
+    const bf16_t* W;
+    void* C;
+    int M, N, K, lda, ldw, ldc;
+    const float* bias;
+    const float* scale;
+    const float* residual;
+    int ldr;
+    int act;
+    int out_bf16;
+};
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int TM = BM / 32, TN = BN / 32;   // 16x16 tiles per wave along m / n (wave tile = BM/2 x BN/2)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, kq = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    // ---- XCD-aware, bijective block -> tile map -----------------------------------------------
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+
+    const int nkt = (p.K + 63) >> 6;
+    const bf16_t* zero = (const bf16_t*)g_zero16;
+
+    auto stage = [&](int buf, int kt) {
+        char* sa = smem + buf * STAGE;
+        char* sb = sa + A_BYTES;
+        const int k0 = kt << 6;
+#pragma unroll
+        for (int i = 0; i < BM * 8 / 256; ++i) {
+            const int qd = i * 256 + tid;
+            const int row = qd >> 3, c = (qd & 7) ^ (row & 7);
+            const int gr = m0 + row, gk = k0 + c * 8;
+            const bf16_t* src = (gr < p.M && gk < p.K) ? p.A + (size_t)gr * p.lda + gk : zero;
+            glds16(src, sa + (i * 256 + wave * 64) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < BN * 8 / 256; ++i) {
+            const int qd = i * 256 + tid;
+            const int row = qd >> 3, c = (qd & 7) ^ (row & 7);
+            const int gr = n0 + row, gk = k0 + c * 8;
+            const bf16_t* src = (gr < p.N && gk < p.K) ? p.W + (size_t)gr * p.ldw + gk : zero;
+            glds16(src, sb + (i * 256 + wave * 64) * 16);
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    stage(0, 0);
+    __syncthreads();   // hipcc waits vmcnt(0) for the LDS-DMA before the barrier
+
+    const int a_row0 = wr * (BM / 2) + fr, b_row0 = wc * (BN / 2) + fr;
+    const int sw = fr & 7;   // (row & 7): every row base is a multiple of 16
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
+        const char* sa = smem + cur * STAGE;
+        const char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int coff = ((s * 4 + kq) ^ sw) << 4;
+            bf16x8 xa[TM], wb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) xa[i] = *(const bf16x8*)(sa + (a_row0 + i * 16) * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wb[j] = *(const bf16x8*)(sb + (b_row0 + j * 16) * 128 + coff);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds C[m][n..n+3],  m = tile row (lane&15),  n = 4*(lane>>4) ----------------
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wr * (BM / 2) + i * 16 + fr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wc * (BN / 2) + j * 16 + kq * 4;
+            if (n >= p.N) continue;
+            f32x4 v = acc[i][j];
+            if (p.bias) {
+                const f32x4 b = *(const f32x4*)(p.bias + n);
+                v += b;
+            }
+            if (p.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            }
+            if (p.scale) {
+                const f32x4 sc = *(const f32x4*)(p.scale + n);
+                v *= sc;
+            }
+            if (p.residual) {
+                const f32x4 rs = *(const f32x4*)(p.residual + (size_t)m * p.ldr + n);
+                v += rs;
+            }
+            if (p.out_bf16) {
+                uint2 o;
+                o.x = pack_bf2(v[0], v[1]);
+                o.y = pack_bf2(v[2], v[3]);
+                *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+            } else {
+                *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN>
+int launch(const GemmParams& p, hipStream_t stream) {
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    constexpr int LDS = 2 * (BM + BN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    gemm_bf16_nt_kernel<BM, BN><<<tiles, 256, LDS, stream>>>(p);
+    MEDP_LAUNCH_CHECK("medp_gemm_bf16_nt");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int medp_gemm_bf16_nt(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldw,
+                                 int ldc, const float* bias, const float* scale, const float* residual, int ldr,
+                                 int act, int out_bf16, void* stream) {
+    MEDP_CHECK_ARG(A && W && C, "gemm: null operand");
+    MEDP_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
+    MEDP_CHECK_ARG(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0, "gemm: K, lda, ldw must be multiples of 8 (16-B chunks)");
+    MEDP_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0, "gemm: N and ldc must be multiples of 4 (vector epilogue)");
+    MEDP_CHECK_ARG(lda >= K && ldw >= K && ldc >= N, "gemm: leading dimension smaller than the row");
+    MEDP_CHECK_ARG(!residual || ldr % 4 == 0, "gemm: ldr must be a multiple of 4");
+    MEDP_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0,
+                   "gemm: operands must be 16-byte aligned");
+    MEDP_CHECK_ARG(act == 0 || act == 1, "gemm: act must be 0 (none) or 1 (gelu)");
+    GemmParams p{(const bf16_t*)A, (const bf16_t*)W, C, M, N, K, lda, ldw, ldc, bias, scale, residual, ldr, act, out_bf16};
+    hipStream_t s = (hipStream_t)stream;
+    if (N <= 64) return launch<128, 64>(p, s);
+    return launch<128, 128>(p, s);
+}

@@ -1,0 +1,288 @@
+// Row normalisations for gfx950: LayerNorm (ViT, perceiver) and ScaleNorm (DuETT encoders), forward + backward.
+// HBM-bound: one 64-lane wave per row, float4 loads, wavefront shuffle reductions, statistics in fp32.
+// The row is read from HBM once (the second/third sweep of the same wave hits L1/L2); the output is written
+// as bf16 when it feeds an MFMA GEMM, as fp32 when it is a residual stream.
+#include "common.h"
+#include "medp_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ LayerNorm fwd
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                            const float* __restrict__ b, void* __restrict__ y, int ldy,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * ldx;
+    const int D4 = D >> 2;
+    float s = 0.f;
+    for (int i = lane; i < D4; i += 64) {
+        const float4 v = *(const float4*)(xr + 4 * i);
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float ss = 0.f;
+    for (int i = lane; i < D4; i += 64) {
+        const float4 v = *(const float4*)(xr + 4 * i);
+        const float a = v.x - mean, c = v.y - mean, d = v.z - mean, e = v.w - mean;
+        ss += (a * a + c * c) + (d * d + e * e);
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+    for (int i = lane; i < D4; i += 64) {
+        const float4 v = *(const float4*)(xr + 4 * i);
+        const float4 ww = *(const float4*)(w + 4 * i);
+        const float4 bb = *(const float4*)(b + 4 * i);
+        const float o0 = (v.x - mean) * rstd * ww.x + bb.x, o1 = (v.y - mean) * rstd * ww.y + bb.y;
+        const float o2 = (v.z - mean) * rstd * ww.z + bb.z, o3 = (v.w - mean) * rstd * ww.w + bb.w;
+        if (OUT_BF16) {
+            uint2 o;
+            o.x = pack_bf2(o0, o1);
+            o.y = pack_bf2(o2, o3);
+            *(uint2*)((bf16_t*)y + (size_t)row * ldy + 4 * i) = o;
+        } else {
+            *(float4*)((float*)y + (size_t)row * ldy + 4 * i) = make_float4(o0, o1, o2, o3);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm bwd (dx)
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w
+__global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x,
+                                                               int ldx, const float* __restrict__ w, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, float* __restrict__ dx, int lddx,
+                                                               int rows, int D, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * ldx;
+    const float* gr = dy + (size_t)row * lddy;
+    const float mu = mean[row], rs = rstd[row];
+    const int D4 = D >> 2;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = lane; i < D4; i += 64) {
+        const float4 v = *(const float4*)(xr + 4 * i), g = *(const float4*)(gr + 4 * i), ww = *(const float4*)(w + 4 * i);
+        const float g0 = g.x * ww.x, g1 = g.y * ww.y, g2 = g.z * ww.z, g3 = g.w * ww.w;
+        s1 += (g0 + g1) + (g2 + g3);
+        s2 += (g0 * (v.x - mu) + g1 * (v.y - mu)) + (g2 * (v.z - mu) + g3 * (v.w - mu));
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) * rs / (float)D;   // mean(g * xhat)
+    float* dr = dx + (size_t)row * lddx;
+    for (int i = lane; i < D4; i += 64) {
+        const float4 v = *(const float4*)(xr + 4 * i), g = *(const float4*)(gr + 4 * i), ww = *(const float4*)(w + 4 * i);
+        float4 o;
+        o.x = rs * (g.x * ww.x - s1 - (v.x - mu) * rs * s2);
+        o.y = rs * (g.y * ww.y - s1 - (v.y - mu) * rs * s2);
+        o.z = rs * (g.z * ww.z - s1 - (v.z - mu) * rs * s2);
+        o.w = rs * (g.w * ww.w - s1 - (v.w - mu) * rs * s2);
+        if (accumulate) {
+            const float4 old = *(const float4*)(dr + 4 * i);
+            o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+        }
+        *(float4*)(dr + 4 * i) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ column reductions
+// partial[chunk][c]        = sum_{r in chunk} dy[r][c] * (x[r][c]-mean[r])*rstd[r]     (MODE 1: LayerNorm dweight)
+// partial[nchunk+chunk][c] = sum_{r in chunk} dy[r][c]                                (bias grad / plain column sum)
+// Deterministic two-stage reduction (no float atomics): results are bitwise reproducible.
+template <int MODE>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             float* __restrict__ partial, int rows, int D, int rows_per_chunk) {
+    __shared__ float red[2][4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int chunk = blockIdx.y, nchunk = gridDim.y;
+    const int r0 = chunk * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    float a = 0.f, bsum = 0.f;
+    if (c < D) {
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const float g = dy[(size_t)r * lddy + c];
+            bsum += g;
+            if (MODE == 1) a += g * (x[(size_t)r * ldx + c] - mean[r]) * rstd[r];
+        }
+    }
+    red[0][rl][cl] = a;
+    red[1][rl][cl] = bsum;
+    __syncthreads();
+    if (rl == 0 && c < D) {
+        if (MODE == 1) partial[(size_t)chunk * D + c] = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+        partial[(size_t)(nchunk + chunk) * D + c] = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out_a,
+                                                           float* __restrict__ out_b, int nchunk, int D) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= D) return;
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < nchunk; ++k) {
+        if (out_a) a += partial[(size_t)k * D + c];
+        b += partial[(size_t)(nchunk + k) * D + c];
+    }
+    if (out_a) out_a[c] = a;
+    if (out_b) out_b[c] = b;
+}
+
+// ------------------------------------------------------------------------------------------------ ScaleNorm
+// y = x / max(||x||_2, eps) * sqrt(D) * g        (x_transformers ScaleNorm; g is a 1-element parameter)
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void scalenorm_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g,
+                                                            void* __restrict__ y, int ldy, float* __restrict__ rnorm_out, int rows,
+                                                            int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * ldx;
+    const int D4 = D >> 2;
+    float ss = 0.f;
+    for (int i = lane; i < D4; i += 64) {
+        const float4 v = *(const float4*)(xr + 4 * i);
+        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    const float rn = 1.0f / fmaxf(sqrtf(wave_sum(ss)), eps);
+    if (lane == 0 && rnorm_out) rnorm_out[row] = rn;
+    const float sc = rn * sqrtf((float)D) * g[0];
+    for (int i = lane; i < D4; i += 64) {
+        const float4 v = *(const float4*)(xr + 4 * i);
+        if (OUT_BF16) {
+            uint2 o;
+            o.x = pack_bf2(v.x * sc, v.y * sc);
+            o.y = pack_bf2(v.z * sc, v.w * sc);
+            *(uint2*)((bf16_t*)y + (size_t)row * ldy + 4 * i) = o;
+        } else {
+            *(float4*)((float*)y + (size_t)row * ldy + 4 * i) = make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc);
+        }
+    }
+}
+
+// dx = s*rn*(dy - x*rn^2*<dy,x>),  s = sqrt(D)*g ;  dg_row = sqrt(D)*rn*<dy,x>   (summed over rows by the caller)
+__global__ __launch_bounds__(256) void scalenorm_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
+                                                            const float* __restrict__ g, const float* __restrict__ rnorm,
+                                                            float* __restrict__ dx, int lddx, float* __restrict__ dg_rows, int rows,
+                                                            int D, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * ldx;
+    const float* gr = dy + (size_t)row * lddy;
+    const int D4 = D >> 2;
+    float dot = 0.f;
+    for (int i = lane; i < D4; i += 64) {
+        const float4 v = *(const float4*)(xr + 4 * i), d = *(const float4*)(gr + 4 * i);
+        dot += (v.x * d.x + v.y * d.y) + (v.z * d.z + v.w * d.w);
+    }
+    dot = wave_sum(dot);
+    const float rn = rnorm[row], sq = sqrtf((float)D);
+    if (lane == 0 && dg_rows) dg_rows[row] = sq * rn * dot;
+    const float s = sq * g[0] * rn, k = rn * rn * dot;
+    float* dr = dx + (size_t)row * lddx;
+    for (int i = lane; i < D4; i += 64) {
+        const float4 v = *(const float4*)(xr + 4 * i), d = *(const float4*)(gr + 4 * i);
+        float4 o = make_float4(s * (d.x - v.x * k), s * (d.y - v.y * k), s * (d.z - v.z * k), s * (d.w - v.w * k));
+        if (accumulate) {
+            const float4 old = *(const float4*)(dr + 4 * i);
+            o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+        }
+        *(float4*)(dr + 4 * i) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void sum_all_kernel(const float* __restrict__ v, float* __restrict__ out, int n) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += v[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+int colsum_chunks(int rows) { return max(1, min(128, rows / 64)); }
+
+}  // namespace
+
+extern "C" int medp_layernorm_fwd(const float* x, int ldx, const float* w, const float* b, void* y, int ldy, int y_bf16,
+                                  float* mean, float* rstd, int rows, int D, float eps, void* stream) {
+    MEDP_CHECK_ARG(x && w && b && y, "layernorm_fwd: null operand");
+    MEDP_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "layernorm_fwd: D, ldx, ldy must be multiples of 4");
+    dim3 grid((rows + 3) / 4);
+    if (y_bf16)
+        layernorm_fwd_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, w, b, y, ldy, mean, rstd, rows, D, eps);
+    else
+        layernorm_fwd_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, w, b, y, ldy, mean, rstd, rows, D, eps);
+    MEDP_LAUNCH_CHECK("medp_layernorm_fwd");
+    return 0;
+}
+
+extern "C" size_t medp_colsum_workspace_bytes(int rows, int D) { return (size_t)2 * colsum_chunks(rows) * D * sizeof(float); }
+
+extern "C" int medp_layernorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* w, const float* mean,
+                                  const float* rstd, float* dx, int lddx, int accumulate_dx, float* dw, float* db,
+                                  float* workspace, int rows, int D, void* stream) {
+    MEDP_CHECK_ARG(dy && x && w && mean && rstd, "layernorm_bwd: null operand");
+    MEDP_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "layernorm_bwd: alignment");
+    hipStream_t s = (hipStream_t)stream;
+    if (dx) {
+        layernorm_bwd_dx_kernel<<<(rows + 3) / 4, 256, 0, s>>>(dy, lddy, x, ldx, w, mean, rstd, dx, lddx, rows, D, accumulate_dx);
+        MEDP_LAUNCH_CHECK("medp_layernorm_bwd(dx)");
+    }
+    if (dw || db) {
+        MEDP_CHECK_ARG(workspace, "layernorm_bwd: workspace required for dw/db (medp_colsum_workspace_bytes)");
+        const int nchunk = colsum_chunks(rows), rpc = (rows + nchunk - 1) / nchunk;
+        colsum_partial_kernel<1><<<dim3((D + 63) / 64, nchunk), 256, 0, s>>>(dy, lddy, x, ldx, mean, rstd, workspace, rows, D, rpc);
+        MEDP_LAUNCH_CHECK("medp_layernorm_bwd(partial)");
+        colsum_final_kernel<<<(D + 255) / 256, 256, 0, s>>>(workspace, dw, db, nchunk, D);
+        MEDP_LAUNCH_CHECK("medp_layernorm_bwd(final)");
+    }
+    return 0;
+}
+
+extern "C" int medp_colsum_f32(const float* x, int ldx, float* out, float* workspace, int rows, int D, void* stream) {
+    MEDP_CHECK_ARG(x && out && workspace && rows > 0 && D > 0, "colsum: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int nchunk = colsum_chunks(rows), rpc = (rows + nchunk - 1) / nchunk;
+    colsum_partial_kernel<0><<<dim3((D + 63) / 64, nchunk), 256, 0, s>>>(x, ldx, nullptr, 0, nullptr, nullptr, workspace, rows, D, rpc);
+    MEDP_LAUNCH_CHECK("medp_colsum_f32(partial)");
+    colsum_final_kernel<<<(D + 255) / 256, 256, 0, s>>>(workspace, nullptr, out, nchunk, D);
+    MEDP_LAUNCH_CHECK("medp_colsum_f32(final)");
+    return 0;
+}
+
+extern "C" int medp_scalenorm_fwd(const float* x, int ldx, const float* g, void* y, int ldy, int y_bf16, float* rnorm, int rows,
+                                  int D, float eps, void* stream) {
+    MEDP_CHECK_ARG(x && g && y, "scalenorm_fwd: null operand");
+    MEDP_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "scalenorm_fwd: D, ldx, ldy must be multiples of 4");
+    dim3 grid((rows + 3) / 4);
+    if (y_bf16)
+        scalenorm_fwd_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, g, y, ldy, rnorm, rows, D, eps);
+    else
+        scalenorm_fwd_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, g, y, ldy, rnorm, rows, D, eps);
+    MEDP_LAUNCH_CHECK("medp_scalenorm_fwd");
+    return 0;
+}
+
+extern "C" int medp_scalenorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* g, const float* rnorm, float* dx,
+                                  int lddx, int accumulate_dx, float* dg, float* workspace_rows, int rows, int D, void* stream) {
+    MEDP_CHECK_ARG(dy && x && g && rnorm && dx, "scalenorm_bwd: null operand");
+    MEDP_CHECK_ARG(rows > 0 && D % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "scalenorm_bwd: alignment");
+    MEDP_CHECK_ARG(!dg || workspace_rows, "scalenorm_bwd: dg needs a rows-float workspace");
+    hipStream_t s = (hipStream_t)stream;
+    scalenorm_bwd_kernel<<<(rows + 3) / 4, 256, 0, s>>>(dy, lddy, x, ldx, g, rnorm, dx, lddx, dg ? workspace_rows : nullptr, rows, D,
+                                                       accumulate_dx);
+    MEDP_LAUNCH_CHECK("medp_scalenorm_bwd");
+    if (dg) {
+        sum_all_kernel<<<1, 256, 0, s>>>(workspace_rows, dg, rows);
+        MEDP_LAUNCH_CHECK("medp_scalenorm_bwd(dg)");
+    }
+    return 0;
+}

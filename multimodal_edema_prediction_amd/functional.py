@@ -1,0 +1,153 @@
+"""Tensor-level wrappers over the C ABI (abi.py): allocate outputs with torch (plumbing), pass raw device
+pointers + the current HIP stream, map return codes to exceptions.  No arithmetic happens in Python."""
+from __future__ import annotations
+
+import torch
+
+from . import abi
+from .abi import check, lib, ptr, stream
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _2d(t: torch.Tensor) -> torch.Tensor:
+    return t.reshape(-1, t.shape[-1])
+
+
+def _ld(t: torch.Tensor) -> int:
+    assert t.dim() == 2 and t.stride(1) == 1, "row-major 2-D view required"
+    return t.stride(0)
+
+
+def to_bf16(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [.., C] -> bf16 (HIP cast kernel)."""
+    x2 = _2d(x)
+    y = torch.empty(x2.shape, dtype=BF16, device=x.device)
+    check(lib().medp_cast_f32_bf16(ptr(x2), _ld(x2), ptr(y), y.stride(0), x2.shape[0], x2.shape[1], stream()), "cast")
+    return y.view(x.shape)
+
+
+def transpose_to_bf16(x: torch.Tensor) -> torch.Tensor:
+    """[R, C] fp32|bf16 -> [C, Rpad] bf16 with Rpad = R rounded up to 8 (zero filled) so it can be a GEMM operand."""
+    x2 = _2d(x)
+    R, C = x2.shape
+    Rp = (R + 7) // 8 * 8
+    y = torch.zeros((C, Rp), dtype=BF16, device=x.device) if Rp != R else torch.empty((C, Rp), dtype=BF16, device=x.device)
+    check(lib().medp_transpose_to_bf16(ptr(x2), int(x2.dtype == BF16), _ld(x2), ptr(y), Rp, R, C, stream()), "transpose")
+    return y
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, scale=None, residual=None, act: int = 0,
+         out_dtype=F32, out: torch.Tensor | None = None, k: int | None = None) -> torch.Tensor:
+    """out[M,N] = epi(a[M,K] @ w[N,K]^T); a, w bf16 row-major (leading dims may exceed K)."""
+    assert a.dtype == BF16 and w.dtype == BF16
+    a2, w2 = _2d(a), _2d(w)
+    M, N = a2.shape[0], w2.shape[0]
+    K = k if k is not None else min(a2.shape[1], w2.shape[1])
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    r2 = _2d(residual) if residual is not None else None
+    check(lib().medp_gemm_bf16_nt(ptr(a2), ptr(w2), ptr(out), M, N, K, _ld(a2), _ld(w2), _ld(out), ptr(bias), ptr(scale),
+                                   ptr(r2), _ld(r2) if r2 is not None else 0, act, int(out.dtype == BF16), stream()), "gemm")
+    return out
+
+
+def layernorm(x: torch.Tensor, w, b, eps: float, out_dtype=BF16, save_stats: bool = False):
+    x2 = _2d(x)
+    rows, D = x2.shape
+    y = torch.empty((rows, D), dtype=out_dtype, device=x.device)
+    mean = torch.empty(rows, dtype=F32, device=x.device) if save_stats else None
+    rstd = torch.empty(rows, dtype=F32, device=x.device) if save_stats else None
+    check(lib().medp_layernorm_fwd(ptr(x2), _ld(x2), ptr(w), ptr(b), ptr(y), D, int(out_dtype == BF16), ptr(mean), ptr(rstd),
+                                    rows, D, eps, stream()), "layernorm_fwd")
+    y = y.view(x.shape)
+    return (y, mean, rstd) if save_stats else y
+
+
+def layernorm_bwd(dy, x, w, mean, rstd, need_dx=True, need_dwdb=True):
+    dy2, x2 = _2d(dy), _2d(x)
+    rows, D = x2.shape
+    dx = torch.empty((rows, D), dtype=F32, device=x.device) if need_dx else None
+    dw = torch.empty(D, dtype=F32, device=x.device) if need_dwdb else None
+    db = torch.empty(D, dtype=F32, device=x.device) if need_dwdb else None
+    ws = torch.empty(lib().medp_colsum_workspace_bytes(rows, D) // 4, dtype=F32, device=x.device) if need_dwdb else None
+    check(lib().medp_layernorm_bwd(ptr(dy2), _ld(dy2), ptr(x2), _ld(x2), ptr(w), ptr(mean), ptr(rstd), ptr(dx), D, 0, ptr(dw),
+                                    ptr(db), ptr(ws), rows, D, stream()), "layernorm_bwd")
+    return (dx.view(x.shape) if need_dx else None), dw, db
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    x2 = _2d(x)
+    rows, D = x2.shape
+    out = torch.empty(D, dtype=F32, device=x.device)
+    ws = torch.empty(lib().medp_colsum_workspace_bytes(rows, D) // 4, dtype=F32, device=x.device)
+    check(lib().medp_colsum_f32(ptr(x2), _ld(x2), ptr(out), ptr(ws), rows, D, stream()), "colsum")
+    return out
+
+
+def scalenorm(x: torch.Tensor, g: torch.Tensor, eps: float = 1e-12, out_dtype=BF16, save_rnorm=False):
+    x2 = _2d(x)
+    rows, D = x2.shape
+    y = torch.empty((rows, D), dtype=out_dtype, device=x.device)
+    rn = torch.empty(rows, dtype=F32, device=x.device) if save_rnorm else None
+    check(lib().medp_scalenorm_fwd(ptr(x2), _ld(x2), ptr(g), ptr(y), D, int(out_dtype == BF16), ptr(rn), rows, D, eps, stream()),
+          "scalenorm_fwd")
+    y = y.view(x.shape)
+    return (y, rn) if save_rnorm else y
+
+
+def scalenorm_bwd(dy, x, g, rnorm, need_dg=True):
+    dy2, x2 = _2d(dy), _2d(x)
+    rows, D = x2.shape
+    dx = torch.empty((rows, D), dtype=F32, device=x.device)
+    dg = torch.empty(1, dtype=F32, device=x.device) if need_dg else None
+    ws = torch.empty(rows, dtype=F32, device=x.device) if need_dg else None
+    check(lib().medp_scalenorm_bwd(ptr(dy2), _ld(dy2), ptr(x2), _ld(x2), ptr(g), ptr(rnorm), ptr(dx), D, 0, ptr(dg), ptr(ws),
+                                    rows, D, stream()), "scalenorm_bwd")
+    return dx.view(x.shape), dg
+
+
+def attn_dh64(qkv: torch.Tensor, B: int, S: int, H: int, scale: float) -> torch.Tensor:
+    """qkv bf16 [B*S, 3*H*64] (q | k | v column blocks) -> o bf16 [B*S, H*64]"""
+    assert qkv.dtype == BF16 and qkv.dim() == 2 and qkv.shape == (B * S, 3 * H * 64)
+    D = H * 64
+    o = torch.empty((B * S, D), dtype=BF16, device=qkv.device)
+    base = qkv.data_ptr()
+    check(lib().medp_attn_fwd_dh64(base, base + 2 * D, base + 4 * D, ptr(o), B, S, H, 3 * D, 3 * D, 3 * D, D, scale, stream()),
+          "attn_fwd_dh64")
+    return o
+
+
+def attn_small_fwd(q, k, v, B, Lq, Lk, H, dh, scale, *, q_batch_stride=None, kv_batch_stride=None, out_dtype=F32,
+                   dropout_p=0.0, seed=0, stream_id=0, attn_avg=None):
+    """q fp32 rows [.., H*dh] (ld = q.stride(-2)); k, v fp32 with a common row stride."""
+    ldq, ldkv = q.stride(-2), k.stride(-2)
+    assert v.stride(-2) == ldkv
+    qbs = Lq * ldq if q_batch_stride is None else q_batch_stride
+    kbs = Lk * ldkv if kv_batch_stride is None else kv_batch_stride
+    o = torch.empty((B, Lq, H * dh), dtype=out_dtype, device=k.device)
+    check(lib().medp_attn_small_fwd(ptr(q), ldq, qbs, ptr(k), ptr(v), ldkv, kbs, ptr(o), H * dh, int(out_dtype == BF16),
+                                     ptr(attn_avg), B, Lq, Lk, H, dh, scale, dropout_p, seed, stream_id, stream()), "attn_small_fwd")
+    return o
+
+
+def attn_small_bwd(dout, q, k, v, B, Lq, Lk, H, dh, scale, *, q_batch_stride=None, kv_batch_stride=None, dropout_p=0.0,
+                   seed=0, stream_id=0):
+    ldq, ldkv = q.stride(-2), k.stride(-2)
+    qbs = Lq * ldq if q_batch_stride is None else q_batch_stride
+    kbs = Lk * ldkv if kv_batch_stride is None else kv_batch_stride
+    D = H * dh
+    dq = torch.empty((B, Lq, D), dtype=F32, device=k.device)
+    dk = torch.empty((B, Lk, D), dtype=F32, device=k.device)
+    dv = torch.empty((B, Lk, D), dtype=F32, device=k.device)
+    d2 = dout.reshape(B * Lq, D)
+    check(lib().medp_attn_small_bwd(ptr(d2), _ld(d2), ptr(q), ldq, qbs, ptr(k), ptr(v), ldkv, kbs, ptr(dq), D, ptr(dk), D, ptr(dv),
+                                     D, B, Lq, Lk, H, dh, scale, dropout_p, seed, stream_id, stream()), "attn_small_bwd")
+    return dq, dk, dv
+
+
+def gelu_bwd(dy: torch.Tensor, pre: torch.Tensor) -> torch.Tensor:
+    dx = torch.empty_like(dy)
+    check(lib().medp_gelu_bwd(ptr(dy), ptr(pre), ptr(dx), dy.numel(), stream()), "gelu_bwd")
+    return dx

@@ -1,0 +1,220 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI (functional.py -> abi.py -> libmedp_hip.so).
+Reference = torch fp32/fp64 on the CPU of the same op on the same (bf16-representable) inputs; tolerances stated inline."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from multimodal_edema_prediction_amd import functional as Fn  # noqa: E402
+
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def bf_round(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def assert_close(got, want, rtol, atol, what=""):
+    got = got.detach().float().cpu().double()
+    want = want.detach().double()
+    err = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    bad = err > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {float(err.max()):.3e} (tol {float(tol.min()):.1e})"
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 768, 768), (16448 // 8, 2304, 768), (300, 72, 2328), (448, 256, 1024),
+                                   (3136 // 4, 2328, 24), (130, 64, 1176), (64, 24, 408), (1000, 512, 792), (256, 3072, 768)])
+def test_gemm_plain(M, N, K):
+    a = bf_round(rnd(M, K, seed=1))
+    w = bf_round(rnd(N, K, seed=2) / math.sqrt(K))
+    want = a.double() @ w.double().T
+    got = Fn.gemm(a.to(DEV).bfloat16(), w.to(DEV).bfloat16())
+    # fp32 accumulation of exact bf16 products: error ~ 1e-6 * sqrt(K) relative to |a||w| row norms
+    assert_close(got, want, 1e-4, 2e-4, f"gemm {M}x{N}x{K}")
+
+
+def test_gemm_identity_asymmetric():
+    """A = I against an ASYMMETRIC W catches a swapped accumulator row/col map (cdna guide §3)."""
+    K = 128
+    a = torch.eye(K)
+    w = torch.arange(256 * K, dtype=torch.float32).reshape(256, K) % 251 - 125.0   # exact in bf16
+    got = Fn.gemm(a.to(DEV).bfloat16(), w.to(DEV).bfloat16())
+    assert torch.equal(got.cpu(), w.T.contiguous())
+
+
+def test_gemm_epilogue_and_strides():
+    M, N, K = 515, 772, 200
+    a_full = bf_round(rnd(M, K + 56, seed=3))          # lda > K
+    w = bf_round(rnd(N, K, seed=4) / math.sqrt(K))
+    bias, scale, res = rnd(N, seed=5), 1 + 0.1 * rnd(N, seed=6), rnd(M, N, seed=7)
+    a = a_full[:, :K]
+    pre = a.double() @ w.double().T + bias.double()
+    want = torch.nn.functional.gelu(pre) * scale.double() + res.double()
+    ad = a_full.to(DEV).bfloat16()[:, :K]
+    got = Fn.gemm(ad, w.to(DEV).bfloat16(), bias=bias.to(DEV), scale=scale.to(DEV), residual=res.to(DEV), act=1)
+    assert_close(got, want, 2e-4, 3e-4, "gemm epilogue fp32")
+    got16 = Fn.gemm(ad, w.to(DEV).bfloat16(), bias=bias.to(DEV), scale=scale.to(DEV), residual=res.to(DEV), act=1,
+                    out_dtype=torch.bfloat16)
+    assert_close(got16, want, 8e-3, 8e-3, "gemm epilogue bf16")     # one bf16 rounding of the result: 2^-8 relative
+    # in-place residual (C aliases the residual), as the ViT block uses it
+    x = res.to(DEV).clone()
+    Fn.gemm(ad, w.to(DEV).bfloat16(), bias=bias.to(DEV), scale=scale.to(DEV), residual=x, out=x)
+    assert_close(x, (a.double() @ w.double().T + bias.double()) * scale.double() + res.double(), 2e-4, 3e-4, "gemm in-place residual")
+
+
+def test_gemm_rejects_bad_arguments():
+    a = torch.zeros(8, 12, device=DEV, dtype=torch.bfloat16)
+    w = torch.zeros(8, 12, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(ValueError):
+        Fn.gemm(a, w)             # K = 12 not a multiple of 8
+    with pytest.raises(RuntimeError):
+        Fn.gemm(torch.zeros(8, 16, dtype=torch.bfloat16), torch.zeros(8, 16, dtype=torch.bfloat16))   # CPU tensors: no fallback
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("rows,D", [(5, 768), (1030, 256), (64 * 7, 256), (9, 2328)])
+def test_layernorm_fwd_bwd(rows, D):
+    x = rnd(rows, D, seed=1) * 2 + 0.3
+    w, b = 1 + 0.1 * rnd(D, seed=2), 0.1 * rnd(D, seed=3)
+    dy = rnd(rows, D, seed=4)
+    xr = x.clone().double().requires_grad_(True)
+    wr, br = w.clone().double().requires_grad_(True), b.clone().double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (D,), wr, br, 1e-5)
+    yr.backward(dy.double())
+    y, mean, rstd = Fn.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5, out_dtype=torch.float32, save_stats=True)
+    assert_close(y, yr, 1e-5, 1e-5, "ln fwd fp32")
+    y16 = Fn.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5, out_dtype=torch.bfloat16)
+    assert_close(y16, yr, 8e-3, 8e-3, "ln fwd bf16")
+    dx, dw, db = Fn.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), mean, rstd)
+    assert_close(dx, xr.grad, 1e-4, 1e-5, "ln dx")
+    assert_close(dw, wr.grad, 1e-4, 1e-4, "ln dw")
+    assert_close(db, br.grad, 1e-4, 1e-4, "ln db")
+
+
+@pytest.mark.parametrize("rows,D", [(7, 408), (3136 // 8, 2328), (100, 1176)])
+def test_scalenorm_fwd_bwd(rows, D):
+    x = rnd(rows, D, seed=1)
+    g = torch.tensor([1.13])
+    dy = rnd(rows, D, seed=2)
+    xr, gr = x.clone().double().requires_grad_(True), g.clone().double().requires_grad_(True)
+    yr = xr / xr.norm(dim=-1, keepdim=True).clamp_min(1e-12) * math.sqrt(D) * gr
+    yr.backward(dy.double())
+    y, rn = Fn.scalenorm(x.to(DEV), g.to(DEV), out_dtype=torch.float32, save_rnorm=True)
+    assert_close(y, yr, 1e-5, 1e-5, "scalenorm fwd")
+    dx, dg = Fn.scalenorm_bwd(dy.to(DEV), x.to(DEV), g.to(DEV), rn)
+    assert_close(dx, xr.grad, 1e-4, 1e-5, "scalenorm dx")
+    assert_close(dg, gr.grad, 1e-4, 1e-3, "scalenorm dg")
+
+
+def test_colsum_and_cast_transpose():
+    x = rnd(1000, 300, seed=1)
+    assert_close(Fn.colsum(x.to(DEV)), x.double().sum(0), 1e-5, 1e-4, "colsum")
+    x4 = rnd(37, 64, seed=2)
+    assert torch.equal(Fn.to_bf16(x4.to(DEV)).cpu(), x4.bfloat16())
+    xt = Fn.transpose_to_bf16(x.to(DEV))
+    assert xt.shape == (300, 1000) and torch.equal(xt.cpu(), x.bfloat16().T.contiguous())
+    xt2 = Fn.transpose_to_bf16(x[:, :99].bfloat16().to(DEV).contiguous())
+    assert torch.equal(xt2.cpu(), x[:, :99].bfloat16().T.contiguous())
+    y = rnd(33, 7, seed=3)         # rows padded to a multiple of 8 with zeros
+    yt = Fn.transpose_to_bf16(y.to(DEV))
+    assert yt.shape == (7, 40) and torch.equal(yt[:, :33].cpu(), y.bfloat16().T.contiguous()) and float(yt[:, 33:].abs().sum()) == 0
+
+
+# ------------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("B,S,H", [(2, 257, 12), (1, 1297, 2), (3, 64, 1), (1, 130, 3), (2, 321, 2)])
+def test_attn_dh64(B, S, H):
+    D = H * 64
+    qkv = bf_round(rnd(B * S, 3 * D, seed=S))
+    q, k, v = [t.reshape(B, S, H, 64).transpose(1, 2).double() for t in qkv.split(D, dim=1)]
+    want = torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1) @ v
+    want = want.transpose(1, 2).reshape(B * S, D)
+    got = Fn.attn_dh64(qkv.to(DEV).bfloat16(), B, S, H, 0.125)
+    # P is rounded to bf16 before the PV product (2^-9 relative per term) and the output once more
+    assert_close(got, want, 1e-2, 1e-2, f"attn_dh64 B{B} S{S} H{H}")
+
+
+def test_attn_dh64_forced_rescale():
+    """A key whose score dominates arrives late: the online-softmax rescale branch must fire (cdna guide rule 26)."""
+    B, S, H = 1, 320, 1
+    qkv = bf_round(rnd(B * S, 192, seed=11) * 0.5)
+    qkv[300, 64:128] = bf_round(qkv[5, 0:64] * 40)          # key 300 aligned with query 5, large
+    q, k, v = [t.reshape(B, S, H, 64).transpose(1, 2).double() for t in qkv.split(64, dim=1)]
+    want = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1) @ v).transpose(1, 2).reshape(S, 64)
+    got = Fn.attn_dh64(qkv.to(DEV).bfloat16(), B, S, H, 0.125)
+    assert_close(got, want, 1e-2, 1e-2, "attn_dh64 rescale")
+
+
+@pytest.mark.parametrize("B,Lq,Lk,H,dh,p", [(3, 7, 256, 4, 64, 0.0), (2, 49, 49, 2, 12, 0.0), (2, 97, 97, 2, 12, 0.0),
+                                            (2, 7, 7, 4, 64, 0.0), (1, 7, 1296, 4, 64, 0.0), (2, 33, 17, 2, 12, 0.0)])
+def test_attn_small_fwd_bwd(B, Lq, Lk, H, dh, p):
+    D = H * dh
+    q, k, v, do = rnd(B, Lq, D, seed=1), rnd(B, Lk, D, seed=2), rnd(B, Lk, D, seed=3), rnd(B, Lq, D, seed=4)
+    scale = dh ** -0.5
+    qr, kr, vr = [t.clone().double().requires_grad_(True) for t in (q, k, v)]
+    sp = lambda t, L: t.view(B, L, H, dh).transpose(1, 2)
+    w = torch.softmax(sp(qr, Lq) @ sp(kr, Lk).transpose(-1, -2) * scale, dim=-1)
+    o = (w @ sp(vr, Lk)).transpose(1, 2).reshape(B, Lq, D)
+    o.backward(do.double())
+    avg = torch.zeros(B, Lq, Lk, device=DEV)
+    got = Fn.attn_small_fwd(q.to(DEV), k.to(DEV), v.to(DEV), B, Lq, Lk, H, dh, scale, attn_avg=avg)
+    assert_close(got, o, 1e-4, 1e-5, "attn_small fwd")
+    assert_close(avg, w.mean(dim=1), 1e-4, 1e-6, "attn_small averaged weights")
+    dq, dk, dv = Fn.attn_small_bwd(do.to(DEV), q.to(DEV), k.to(DEV), v.to(DEV), B, Lq, Lk, H, dh, scale)
+    assert_close(dq, qr.grad, 1e-4, 1e-5, "attn_small dq")
+    assert_close(dk, kr.grad, 1e-4, 1e-5, "attn_small dk")
+    assert_close(dv, vr.grad, 1e-4, 1e-5, "attn_small dv")
+
+
+def test_attn_small_shared_query_and_strided_kv():
+    """Perceiver cross blocks: one [7,256] query shared by the batch (batch stride 0) over keys that skip the CLS row."""
+    B, Lq, Lk, H, dh = 3, 7, 16, 4, 64
+    D = H * dh
+    q = rnd(Lq, D, seed=1)
+    kv = rnd(B, Lk + 1, 2 * D, seed=2)                    # [k | v] fused rows, first row of each batch (CLS) skipped
+    k, v = kv[:, 1:, :D], kv[:, 1:, D:]
+    sp = lambda t, L: t.reshape(-1, L, H, dh).transpose(1, 2).double()
+    w = torch.softmax(sp(q.expand(B, -1, -1), Lq) @ sp(k, Lk).transpose(-1, -2) * dh ** -0.5, dim=-1)
+    want = (w @ sp(v, Lk)).transpose(1, 2).reshape(B, Lq, D)
+    kvd = kv.to(DEV)
+    got = Fn.attn_small_fwd(q.to(DEV), kvd[:, 1:, :D], kvd[:, 1:, D:], B, Lq, Lk, H, dh, dh ** -0.5, q_batch_stride=0,
+                            kv_batch_stride=(Lk + 1) * 2 * D)
+    assert_close(got, want, 1e-4, 1e-5, "attn_small shared q / strided kv")
+
+
+def test_attn_small_dropout_consistent_between_fwd_and_bwd():
+    """With dropout on, backward must regenerate the forward's mask: check dV = P_dropped^T dO via linearity in V."""
+    B, Lq, Lk, H, dh, p = 2, 7, 64, 4, 64, 0.25
+    D = H * dh
+    q, k, v, do = rnd(B, Lq, D, seed=1), rnd(B, Lk, D, seed=2), rnd(B, Lk, D, seed=3), rnd(B, Lq, D, seed=4)
+    args = dict(dropout_p=p, seed=123, stream_id=5)
+    o1 = Fn.attn_small_fwd(q.to(DEV), k.to(DEV), v.to(DEV), B, Lq, Lk, H, dh, 0.125, **args)
+    o2 = Fn.attn_small_fwd(q.to(DEV), k.to(DEV), v.to(DEV), B, Lq, Lk, H, dh, 0.125, **args)
+    assert torch.equal(o1, o2)                                           # deterministic in (seed, stream)
+    o0 = Fn.attn_small_fwd(q.to(DEV), k.to(DEV), v.to(DEV), B, Lq, Lk, H, dh, 0.125)
+    assert not torch.allclose(o1, o0)
+    _, _, dv = Fn.attn_small_bwd(do.to(DEV), q.to(DEV), k.to(DEV), v.to(DEV), B, Lq, Lk, H, dh, 0.125, **args)
+    # <dO, o(V)> is linear in V with gradient dV: <dV, V> must equal <dO, o1>
+    lhs = float((dv.double() * v.to(DEV).double()).sum())
+    rhs = float((do.to(DEV).double() * o1.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(rhs))
+    avg = torch.zeros(B, Lq, Lk, device=DEV)
+    Fn.attn_small_fwd(q.to(DEV), k.to(DEV), v.to(DEV), B, Lq, Lk, H, dh, 0.125, attn_avg=avg, **args)
+    frac_zero = float((avg == 0).float().mean())
+    assert 0.0 < frac_zero < 0.05            # a weight is zero in the head-average only if all 4 heads dropped it (p^4 = 0.4 %)
+
+
+def test_gelu_bwd():
+    pre, dy = rnd(64, 100, seed=1) * 2, rnd(64, 100, seed=2)
+    pr = pre.clone().double().requires_grad_(True)
+    torch.nn.functional.gelu(pr).backward(dy.double())
+    assert_close(Fn.gelu_bwd(dy.to(DEV), pre.to(DEV)), pr.grad, 1e-5, 1e-6, "gelu bwd")
