@@ -51,9 +51,9 @@ int medp_attn_small_fwd(const float* q, int ldq, long long q_batch_stride, const
                         long long kv_batch_stride, void* o, int ldo, int o_bf16, float* attn_avg, int B, int Lq, int Lk,
                         int H, int dh, float scale, float dropout_p, unsigned seed, unsigned stream_id, void* stream);
 int medp_attn_small_bwd(const float* dout, int lddo, const float* q, int ldq, long long q_batch_stride, const float* k,
-                        const float* v, int ldkv, long long kv_batch_stride, float* dq, int lddq, float* dk, int lddk,
-                        float* dv, int lddv, int B, int Lq, int Lk, int H, int dh, float scale, float dropout_p,
-                        unsigned seed, unsigned stream_id, void* stream);
+                        const float* v, int ldkv, long long kv_batch_stride, float* dq, int lddq, float* dk, int lddkv,
+                        float* dv, int reserved, long long dkv_batch_stride, int B, int Lq, int Lk, int H, int dh, float scale,
+                        float dropout_p, unsigned seed, unsigned stream_id, void* stream);
 
 /* ---- normalisation -------------------------------------------------------------------------------- */
 /* nn.LayerNorm (modeling_dinov2.py:348,353 eps 1e-6; model :750-753 eps 1e-5).  y is bf16 (feeds a GEMM) or fp32. */
@@ -109,6 +109,90 @@ size_t medp_vit_workspace_bytes(const MedpVitWeights* host_w, int B, int H, int 
 /* pixels fp32 [B,3,H,W] -> tokens_f32 [B, P+1, hidden] (may be NULL) and/or tokens_bf16 (may be NULL) after the final LN */
 int medp_vit_forward(const MedpVitWeights* host_w, const float* pixels, int B, int H, int W, float* tokens_f32,
                      void* tokens_bf16, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- whole-module forward of the DuETT backbone in inference form: DuettFeatureExtractor.encode (model :31-94) -----
+ * BatchNorm layers are folded by the caller into (scale, shift) = (w/sqrt(var+eps), b - mean*scale): eval-mode
+ * BatchNormLastDim (duett/duett.py:11-22).  Encoder = x_transformers.Encoder(depth=1) (duett/duett.py:95-105),
+ * restated in oracle/xt_encoder.py (parity unpinned at that boundary). */
+typedef struct {
+    const float* g_attn;          /* ScaleNorm gain before attention [1] */
+    const void* qkv_w;            /* bf16 [3*E, D]: to_q | to_k | to_v rows (no bias) */
+    const void* out_w;            /* bf16 [D, E]   to_out (no bias) */
+    const float* g_ff;            /* ScaleNorm gain before the feed-forward [1] */
+    const void* ff1_w;            /* bf16 [d_ff, D] */
+    const float* ff1_b;
+    const void* ff2_w;            /* bf16 [D, d_ff] */
+    const float* ff2_b;
+    const float* g_final;         /* final ScaleNorm gain [1] (used when final_norm != 0) */
+} MedpEncoderWeights;
+
+typedef struct {
+    int n_vars, n_static, d_embedding, n_heads, n_layers, d_ff, d_hidden_embed, d_hidden_tab, d_hidden_time, n_obs_rows,
+        final_norm;
+    float norm_eps;
+    /* per-variable embedding MLPs stacked over V: Linear(2,64) -> ReLU -> BN -> Linear(64,E)  (duett.py:84-86) */
+    const void *emb_w0, *emb_b0, *emb_bn_scale, *emb_bn_shift, *emb_w4, *emb_b4;   /* fp32 [V,64,2] [V,64] [V,64] [V,64] [V,E,64] [V,E] */
+    const void* n_obs_table;      /* fp32 [n_obs_rows] (n_obs_embedding.weight[:,0]) */
+    const void *tab_w0, *tab_b0, *tab_bn_scale, *tab_bn_shift, *tab_w4, *tab_b4;   /* tab_encoder (duett.py:124-125) */
+    const void* special;          /* fp32 [8, E] special_embeddings */
+    const void *time_w0, *time_b0, *time_bn_scale, *time_bn_shift, *time_w3, *time_b3;   /* full_time_embedding = cve (duett.py:151-157) */
+    const void* rep_embedding;    /* fp32 [tt_dim]  full_rep_embedding.weight[:,0] */
+    const void* event_embedding;  /* fp32 [V+1, et_dim] full_event_embedding.weight */
+    const MedpEncoderWeights* event_enc;   /* HOST arrays of n_layers entries */
+    const MedpEncoderWeights* time_enc;
+} MedpDuettWeights;
+
+size_t medp_duett_workspace_bytes(const MedpDuettWeights* host_w, int B, int T);
+/* xs_static [B,Ds], xs_ts [B,T,2V+1], xs_times [B,T] fp32 (outputs of feats_to_input) -> tokens [B, T+1, E*(V+1)];
+ * psi0_out (optional, [B,T+1,V+1,E]) receives psi after the embedding stage for parity checks. */
+int medp_duett_encode(const MedpDuettWeights* host_w, const float* xs_static, const float* xs_ts, const float* xs_times, int B,
+                      int T, float* tokens_f32, void* tokens_bf16, float* psi0_out, void* workspace, size_t workspace_bytes,
+                      void* stream);
+
+/* ---- fusion head pointwise ops (fp32), dropout masks regenerated from (seed, stream_id, element index) --------- */
+int medp_gelu_dropout_fwd(const float* x, float* y, long long n, float p, unsigned seed, unsigned stream_id, void* stream);
+int medp_gelu_dropout_bwd(const float* dy, const float* x, float* dx, long long n, float p, unsigned seed, unsigned stream_id,
+                          void* stream);
+/* out = residual + dropout(y) (residual may be NULL; backward = same call on the incoming gradient with residual NULL) */
+int medp_dropout_add(const float* y, const float* residual, float* out, long long n, float p, unsigned seed, unsigned stream_id,
+                     void* stream);
+/* Linear(D,1) output layer of the pathology heads (model :574,:590) */
+int medp_rowdot_fwd(const float* x, int ldx, const float* w, const float* b, float* y, int rows, int D, void* stream);
+int medp_rowdot_bwd(const float* dy, const float* x, int ldx, const float* w, float* dx, float* dw, float* db, int rows, int D,
+                    void* stream);
+/* per-label biases + residual fusion  fusion = img.detach() + beta*correction  (model :634-639) */
+int medp_fusion_logits_fwd(const float* hi, const float* ht, const float* hc, const float* img_bias, const float* ts_bias,
+                           const float* beta, float* img, float* ts, float* scaled, float* fus, int B, int K, void* stream);
+int medp_fusion_logits_bwd(const float* d_img, const float* d_ts, const float* d_scaled, const float* d_fus, const float* hc,
+                           const float* beta, float* d_hi, float* d_ht, float* d_hc, float* d_img_bias, float* d_ts_bias,
+                           float* d_beta, int B, int K, void* stream);
+/* StudentModel pool="mean" over the T hourly tokens of [B, T1, D] (model :1231) */
+int medp_meanpool_fwd(const float* x, float* y, int B, int T, int T1, int D, void* stream);
+int medp_meanpool_bwd(const float* dy, float* dx, int B, int T, int T1, int D, void* stream);
+
+/* ---- losses: value + gradient in one launch ------------------------------------------------------------------------
+ * DualPathologyLoss (loss/losses_duett.py:131-194).  out: [0] total, [1] img_total, [2] ts_total, [3] fus_total,
+ * [4..4+3K) img_per | ts_per | fus_per.  g_*: d total / d logits (any may be NULL).  pos_weight may be NULL. */
+int medp_dual_pathology_loss(const float* img, const float* ts, const float* fus, const float* y, const float* mask,
+                             const float* label_weights, const float* pos_weight, float alpha_img, float alpha_ts,
+                             float alpha_fus, float eps, float* out, float* g_img, float* g_ts, float* g_fus, int B, int K,
+                             void* stream);
+/* StudentKDLoss + VanillaKLKD (loss/losses_duett.py:8-57).  out: [0] total [1] bce [2] kd.  pos_weight = 1 for none. */
+int medp_student_kd_loss(const float* z_s, const float* z_t, const float* y, float T, float alpha, float pos_weight, float* out,
+                         float* g_zs, int B, void* stream);
+
+/* ---- optimiser: torch.optim.AdamW semantics over a device table of tensors (trainer.py:77-116,383) -------------- */
+typedef struct {
+    void* param;            /* fp32, updated in place */
+    const void* grad;       /* fp32 */
+    void* exp_avg;          /* fp32 */
+    void* exp_avg_sq;       /* fp32 */
+    long long numel;
+    float lr, weight_decay;
+} MedpAdamTensor;
+int medp_adamw_chunk_elems(void);   /* elements one workgroup updates; block b handles chunk dev_block_chunk[b] of tensor dev_block_tensor[b] */
+int medp_adamw_multi(const MedpAdamTensor* dev_descs, const int* dev_block_tensor, const int* dev_block_chunk, int n_blocks,
+                     float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -45,6 +45,10 @@ class MedpDuettWeights(ctypes.Structure):
                 + [("event_enc", ctypes.POINTER(MedpEncoderWeights)), ("time_enc", ctypes.POINTER(MedpEncoderWeights))])
 
 
+class MedpAdamTensor(ctypes.Structure):
+    _fields_ = [("param", P), ("grad", P), ("exp_avg", P), ("exp_avg_sq", P), ("numel", LL), ("lr", F), ("weight_decay", F)]
+
+
 # name -> (restype, argtypes); must list every function declared in include/medp_hip.h (tests/test_abi.py checks)
 SIGNATURES = {
     "medp_last_error": (c_char_p, []),
@@ -53,7 +57,7 @@ SIGNATURES = {
     "medp_gemm_bf16_nt": (I, [P, P, P, I, I, I, I, I, I, P, P, P, I, I, I, P]),
     "medp_attn_fwd_dh64": (I, [P, P, P, P, I, I, I, I, I, I, I, F, P]),
     "medp_attn_small_fwd": (I, [P, I, LL, P, P, I, LL, P, I, I, P, I, I, I, I, I, F, F, U, U, P]),
-    "medp_attn_small_bwd": (I, [P, I, P, I, LL, P, P, I, LL, P, I, P, I, P, I, I, I, I, I, I, F, F, U, U, P]),
+    "medp_attn_small_bwd": (I, [P, I, P, I, LL, P, P, I, LL, P, I, P, I, P, I, LL, I, I, I, I, I, F, F, U, U, P]),
     "medp_layernorm_fwd": (I, [P, I, P, P, P, I, I, P, P, I, I, F, P]),
     "medp_colsum_workspace_bytes": (SZ, [I, I]),
     "medp_layernorm_bwd": (I, [P, I, P, I, P, P, P, P, I, I, P, P, P, I, I, P]),
@@ -68,6 +72,21 @@ SIGNATURES = {
     "medp_pos_embed_bicubic": (I, [P, P, I, I, I, I, P]),
     "medp_vit_workspace_bytes": (SZ, [ctypes.POINTER(MedpVitWeights), I, I, I]),
     "medp_vit_forward": (I, [ctypes.POINTER(MedpVitWeights), P, I, I, I, P, P, P, SZ, P]),
+    "medp_duett_workspace_bytes": (SZ, [ctypes.POINTER(MedpDuettWeights), I, I]),
+    "medp_duett_encode": (I, [ctypes.POINTER(MedpDuettWeights), P, P, P, I, I, P, P, P, P, SZ, P]),
+    "medp_gelu_dropout_fwd": (I, [P, P, LL, F, U, U, P]),
+    "medp_gelu_dropout_bwd": (I, [P, P, P, LL, F, U, U, P]),
+    "medp_dropout_add": (I, [P, P, P, LL, F, U, U, P]),
+    "medp_rowdot_fwd": (I, [P, I, P, P, P, I, I, P]),
+    "medp_rowdot_bwd": (I, [P, P, I, P, P, P, P, I, I, P]),
+    "medp_fusion_logits_fwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, P]),
+    "medp_fusion_logits_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, P]),
+    "medp_meanpool_fwd": (I, [P, P, I, I, I, I, P]),
+    "medp_meanpool_bwd": (I, [P, P, I, I, I, I, P]),
+    "medp_dual_pathology_loss": (I, [P, P, P, P, P, P, P, F, F, F, F, P, P, P, P, I, I, P]),
+    "medp_student_kd_loss": (I, [P, P, P, F, F, F, P, P, I, P]),
+    "medp_adamw_chunk_elems": (I, []),
+    "medp_adamw_multi": (I, [P, P, P, I, F, F, F, I, F, P]),
 }
 
 _lib = None

@@ -1,0 +1,318 @@
+"""torch.autograd.Function wrappers: each forward/backward is one or a few HIP launches through the C ABI.
+Autograd is used as bookkeeping only (which op's backward runs when, and where gradients accumulate); every
+arithmetic step is a kernel of libmedp_hip.  Tensors visible to autograd are fp32; GEMM operands are cast to
+bf16 inside `LinearFn` (weights are cached per parameter version), accumulation is fp32.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import functional as Fn
+from .abi import check, lib, ptr, stream
+
+F32, BF16 = torch.float32, torch.bfloat16
+
+# ---------------------------------------------------------------------------------------------- weight caches
+_W_CACHE: dict = {}
+
+
+def _cached(t: torch.Tensor, kind: str, make):
+    key = (t.data_ptr(), tuple(t.shape), kind)
+    ver = t._version
+    hit = _W_CACHE.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    val = make(t.detach())
+    _W_CACHE[key] = (ver, val)
+    return val
+
+
+def weight_bf16(w: torch.Tensor) -> torch.Tensor:
+    return _cached(w, "bf16", lambda t: Fn.to_bf16(t.contiguous()) if t.shape[-1] % 4 == 0 else t.to(BF16))
+
+
+def weight_t_bf16(w: torch.Tensor) -> torch.Tensor:
+    """[N,K] fp32 -> [K, Npad8] bf16 (operand of dX = dY · W)."""
+    return _cached(w, "t_bf16", lambda t: Fn.transpose_to_bf16(t.contiguous()))
+
+
+_SEED_STATE = {"n": 0}
+
+
+def next_seed() -> int:
+    """One 31-bit seed per forward call, drawn from torch's CPU generator (so torch.manual_seed controls dropout)."""
+    return int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+
+
+# ---------------------------------------------------------------------------------------------- Linear
+class LinearFn(torch.autograd.Function):
+    """y = x W^T (+ b) (+ residual).  x: [..., K] fp32 or bf16; W: [N, K] fp32; y fp32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual):
+        xb = x if x.dtype == BF16 else Fn.to_bf16(x.contiguous())
+        x2 = xb.reshape(-1, xb.shape[-1])
+        wb = weight_bf16(weight)
+        res2 = residual.reshape(-1, weight.shape[0]).contiguous() if residual is not None else None
+        y = Fn.gemm(x2, wb, bias=bias, residual=res2, out_dtype=F32, k=weight.shape[1])
+        ctx.save_for_backward(x2, weight)
+        ctx.x_shape = x.shape
+        ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
+        ctx.x_needs = x.requires_grad if isinstance(x, torch.Tensor) else False
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        N, K = weight.shape
+        dy2 = dy.reshape(-1, N).contiguous()
+        dx = dw = db = None
+        dyb = None
+        if ctx.needs_input_grad[0]:
+            dyb = Fn.to_bf16(dy2) if N % 4 == 0 else dy2.to(BF16)
+            wt = weight_t_bf16(weight)                           # [K, Npad]
+            dx = Fn.gemm(dyb, wt, out_dtype=F32, k=N).view(ctx.x_shape)
+        if ctx.needs_input_grad[1]:
+            dyt = Fn.transpose_to_bf16(dy2)                      # [N, Mpad]
+            xt = Fn.transpose_to_bf16(x2)                        # [K, Mpad]
+            dw = Fn.gemm(dyt, xt, out_dtype=F32, k=dyt.shape[1])  # [N, K]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = Fn.colsum(dy2)
+        dres = dy if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        return dx, dw, db, dres
+
+
+def linear(x, weight, bias=None, residual=None):
+    return LinearFn.apply(x, weight, bias, residual)
+
+
+# ---------------------------------------------------------------------------------------------- LayerNorm
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        xc = x.contiguous()
+        y, mean, rstd = Fn.layernorm(xc, w, b, eps, out_dtype=F32, save_stats=True)
+        ctx.save_for_backward(xc, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        dx, dw, db = Fn.layernorm_bwd(dy.contiguous(), x, w, mean, rstd, need_dx=ctx.needs_input_grad[0],
+                                      need_dwdb=ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        return dx, dw, db, None
+
+
+def layer_norm(x, w, b, eps=1e-5):
+    return LayerNormFn.apply(x, w, b, eps)
+
+
+# ---------------------------------------------------------------------------------------------- GELU (+dropout), dropout+add
+class GeluDropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed, sid):
+        xc = x.contiguous()
+        y = torch.empty_like(xc)
+        check(lib().medp_gelu_dropout_fwd(ptr(xc), ptr(y), xc.numel(), p, seed, sid, stream()), "gelu_dropout_fwd")
+        ctx.save_for_backward(xc)
+        ctx.cfg = (p, seed, sid)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        p, seed, sid = ctx.cfg
+        dyc = dy.contiguous()
+        dx = torch.empty_like(x)
+        check(lib().medp_gelu_dropout_bwd(ptr(dyc), ptr(x), ptr(dx), x.numel(), p, seed, sid, stream()), "gelu_dropout_bwd")
+        return dx, None, None, None
+
+
+def gelu_dropout(x, p=0.0, seed=0, sid=0):
+    return GeluDropoutFn.apply(x, float(p), int(seed), int(sid))
+
+
+class DropoutAddFn(torch.autograd.Function):
+    """out = residual + dropout(y)."""
+
+    @staticmethod
+    def forward(ctx, y, residual, p, seed, sid):
+        yc, rc = y.contiguous(), residual.contiguous()
+        out = torch.empty_like(yc)
+        check(lib().medp_dropout_add(ptr(yc), ptr(rc), ptr(out), yc.numel(), p, seed, sid, stream()), "dropout_add")
+        ctx.cfg = (p, seed, sid)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        p, seed, sid = ctx.cfg
+        dc = dout.contiguous()
+        dy = torch.empty_like(dc)
+        check(lib().medp_dropout_add(ptr(dc), None, ptr(dy), dc.numel(), p, seed, sid, stream()), "dropout_add(bwd)")
+        return dy, dout, None, None, None
+
+
+def dropout_add(y, residual, p, seed, sid):
+    return DropoutAddFn.apply(y, residual, float(p), int(seed), int(sid))
+
+
+# ---------------------------------------------------------------------------------------------- attention
+class AttnSmallFn(torch.autograd.Function):
+    """Multi-head attention core.  q: [Lq, D] (shared by the batch) or [B, Lq, D]; kv: [B, Lk(+skip), 2D] fused K|V
+    projection, of which rows `skip:` are attended (skip=1 drops the CLS row of the image tokens).  Returns
+    ([B, Lq, D], attn_avg or None)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, H, scale, p, seed, sid, skip, want_avg):
+        q, kv = q.contiguous(), kv.contiguous()
+        shared = q.dim() == 2
+        B, Ltot, D2 = kv.shape
+        D, Lk = D2 // 2, Ltot - skip
+        Lq = q.shape[-2]
+        dh = D // H
+        kview = kv[:, skip:, :D]
+        vview = kv[:, skip:, D:]
+        avg = torch.zeros((B, Lq, Lk), dtype=F32, device=kv.device) if want_avg else None
+        o = Fn.attn_small_fwd(q, kview, vview, B, Lq, Lk, H, dh, scale, q_batch_stride=0 if shared else None,
+                              kv_batch_stride=kv.stride(0), dropout_p=p, seed=seed, stream_id=sid, attn_avg=avg)
+        ctx.save_for_backward(q, kv)
+        ctx.cfg = (H, scale, p, seed, sid, skip, shared)
+        if want_avg:
+            ctx.mark_non_differentiable(avg)
+        return o, avg
+
+    @staticmethod
+    def backward(ctx, do, _davg):
+        q, kv = ctx.saved_tensors
+        H, scale, p, seed, sid, skip, shared = ctx.cfg
+        B, Ltot, D2 = kv.shape
+        D, Lk = D2 // 2, Ltot - skip
+        Lq = q.shape[-2]
+        dkv = torch.zeros_like(kv) if skip else torch.empty_like(kv)
+        dq, _, _ = Fn.attn_small_bwd(do.contiguous(), q, kv[:, skip:, :D], kv[:, skip:, D:], B, Lq, Lk, H, D // H, scale,
+                                     q_batch_stride=0 if shared else None, kv_batch_stride=kv.stride(0), dropout_p=p, seed=seed,
+                                     stream_id=sid, dkv_out=dkv[:, skip:, :])
+        if shared:
+            dq = Fn.colsum(dq.view(B, Lq * D)).view(Lq, D)
+        return dq, dkv, None, None, None, None, None, None, None
+
+
+def attn_small(q, kv, H, scale, p=0.0, seed=0, sid=0, skip=0, want_avg=False):
+    return AttnSmallFn.apply(q, kv, int(H), float(scale), float(p), int(seed), int(sid), int(skip), bool(want_avg))
+
+
+# ---------------------------------------------------------------------------------------------- heads / logits
+class RowDotFn(torch.autograd.Function):
+    """y[m] = <x[m,:], w[0,:]> + b   (nn.Linear(D, 1))."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        y = torch.empty(x2.shape[0], dtype=F32, device=x.device)
+        check(lib().medp_rowdot_fwd(ptr(x2), x2.stride(0), ptr(w), ptr(b), ptr(y), x2.shape[0], x2.shape[1], stream()), "rowdot_fwd")
+        ctx.save_for_backward(x2, w)
+        ctx.has_b = b is not None
+        ctx.x_shape = x.shape
+        return y.view(x.shape[:-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        dyc = dy.reshape(-1).contiguous()
+        dx = torch.empty_like(x2)
+        dw = torch.empty_like(w)
+        db = torch.empty(1, dtype=F32, device=w.device) if ctx.has_b else None
+        check(lib().medp_rowdot_bwd(ptr(dyc), ptr(x2), x2.stride(0), ptr(w), ptr(dx), ptr(dw), ptr(db), x2.shape[0], x2.shape[1], stream()),
+              "rowdot_bwd")
+        return dx.view(ctx.x_shape), dw, db
+
+
+def rowdot(x, w, b=None):
+    return RowDotFn.apply(x, w, b)
+
+
+class FusionLogitsFn(torch.autograd.Function):
+    """(img, ts, scaled, fus) from the three head outputs; `fus = img.detach() + beta*corr` (model :634-639)."""
+
+    @staticmethod
+    def forward(ctx, hi, ht, hc, ib, tb, beta):
+        hi, ht, hc = hi.contiguous(), ht.contiguous(), hc.contiguous()
+        B, K = hi.shape
+        img, ts, scaled, fus = (torch.empty_like(hi) for _ in range(4))
+        check(lib().medp_fusion_logits_fwd(ptr(hi), ptr(ht), ptr(hc), ptr(ib), ptr(tb), ptr(beta), ptr(img), ptr(ts), ptr(scaled),
+                                           ptr(fus), B, K, stream()), "fusion_logits_fwd")
+        ctx.save_for_backward(hc, beta)
+        return img, ts, scaled, fus
+
+    @staticmethod
+    def backward(ctx, d_img, d_ts, d_scaled, d_fus):
+        hc, beta = ctx.saved_tensors
+        B, K = hc.shape
+        c = lambda t: t.contiguous() if t is not None else None
+        d_img, d_ts, d_scaled, d_fus = c(d_img), c(d_ts), c(d_scaled), c(d_fus)
+        d_hi, d_ht, d_hc = (torch.empty_like(hc) for _ in range(3))
+        d_ib, d_tb, d_beta = (torch.empty(K, dtype=F32, device=hc.device) for _ in range(3))
+        check(lib().medp_fusion_logits_bwd(ptr(d_img), ptr(d_ts), ptr(d_scaled), ptr(d_fus), ptr(hc), ptr(beta), ptr(d_hi), ptr(d_ht),
+                                           ptr(d_hc), ptr(d_ib), ptr(d_tb), ptr(d_beta), B, K, stream()), "fusion_logits_bwd")
+        return d_hi, d_ht, d_hc, d_ib, d_tb, d_beta
+
+
+class MeanPoolFn(torch.autograd.Function):
+    """mean over tokens [:, :T] of [B, T1, D]."""
+
+    @staticmethod
+    def forward(ctx, x, T):
+        xc = x.contiguous()
+        B, T1, D = xc.shape
+        y = torch.empty((B, D), dtype=F32, device=x.device)
+        check(lib().medp_meanpool_fwd(ptr(xc), ptr(y), B, T, T1, D, stream()), "meanpool_fwd")
+        ctx.cfg = (B, T, T1, D)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, T, T1, D = ctx.cfg
+        dyc = dy.contiguous()
+        dx = torch.empty((B, T1, D), dtype=F32, device=dy.device)
+        check(lib().medp_meanpool_bwd(ptr(dyc), ptr(dx), B, T, T1, D, stream()), "meanpool_bwd")
+        return dx, None
+
+
+# ---------------------------------------------------------------------------------------------- losses
+class DualPathologyLossFn(torch.autograd.Function):
+    """Returns the [4+3K] vector of medp_dual_pathology_loss; element 0 is the differentiable total."""
+
+    @staticmethod
+    def forward(ctx, img, ts, fus, y, mask, lw, pw, a_img, a_ts, a_fus, eps):
+        img, ts, fus, y, mask = (t.contiguous().to(F32) for t in (img, ts, fus, y, mask))
+        B, K = img.shape
+        out = torch.empty(4 + 3 * K, dtype=F32, device=img.device)
+        g = [torch.empty_like(img) for _ in range(3)]
+        check(lib().medp_dual_pathology_loss(ptr(img), ptr(ts), ptr(fus), ptr(y), ptr(mask), ptr(lw), ptr(pw), a_img, a_ts, a_fus, eps,
+                                             ptr(out), ptr(g[0]), ptr(g[1]), ptr(g[2]), B, K, stream()), "dual_pathology_loss")
+        ctx.save_for_backward(*g)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        g_img, g_ts, g_fus = ctx.saved_tensors
+        s = dout[0]
+        return g_img * s, g_ts * s, g_fus * s, None, None, None, None, None, None, None, None
+
+
+class StudentKDLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z_s, z_t, y, T, alpha, pos_weight):
+        z_s, z_t, y = (t.contiguous().to(F32) for t in (z_s, z_t, y))
+        out = torch.empty(3, dtype=F32, device=z_s.device)
+        g = torch.empty_like(z_s)
+        check(lib().medp_student_kd_loss(ptr(z_s), ptr(z_t), ptr(y), T, alpha, pos_weight, ptr(out), ptr(g), z_s.numel(), stream()),
+              "student_kd_loss")
+        ctx.save_for_backward(g)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (g,) = ctx.saved_tensors
+        return g * dout[0], None, None, None, None, None

@@ -107,7 +107,7 @@ constexpr int QCH = 8;
 template <int NPER>
 __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const SmallAttnParams p, const float* __restrict__ dout, int lddo,
                                                              float* __restrict__ dq, int lddq, float* __restrict__ dk, int lddk,
-                                                             float* __restrict__ dv, int lddv) {
+                                                             float* __restrict__ dv, int lddv, long long dkv_bs) {
     extern __shared__ float sm[];
     // layout: P[QCH][Lk], dS[QCH][Lk], qrows[QCH][dh], dorows[QCH][dh]
     float* sP = sm;
@@ -118,8 +118,8 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const SmallAttnPara
     const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const float* kbase = p.k + (size_t)b * p.kv_bs + h * p.dh;
     const float* vbase = p.v + (size_t)b * p.kv_bs + h * p.dh;
-    float* dkbase = dk + (size_t)b * p.Lk * lddk + h * p.dh;
-    float* dvbase = dv + (size_t)b * p.Lk * lddv + h * p.dh;
+    float* dkbase = dk + (size_t)b * dkv_bs + h * p.dh;
+    float* dvbase = dv + (size_t)b * dkv_bs + h * p.dh;
     constexpr int nper = NPER;
     float pj[NPER];
 
@@ -213,8 +213,10 @@ extern "C" int medp_attn_small_fwd(const float* q, int ldq, long long q_batch_st
 
 extern "C" int medp_attn_small_bwd(const float* dout, int lddo, const float* q, int ldq, long long q_batch_stride, const float* k,
                                    const float* v, int ldkv, long long kv_batch_stride, float* dq, int lddq, float* dk, int lddk,
-                                   float* dv, int lddv, int B, int Lq, int Lk, int H, int dh, float scale, float dropout_p,
-                                   unsigned seed, unsigned stream_id, void* stream) {
+                                   float* dv, int lddkv_unused, long long dkv_batch_stride, int B, int Lq, int Lk, int H, int dh,
+                                   float scale, float dropout_p, unsigned seed, unsigned stream_id, void* stream) {
+    const int lddv = lddk;
+    (void)lddkv_unused;
     SmallAttnParams p{q, k, v, ldq, ldkv, ldkv, q_batch_stride, kv_batch_stride, B, Lq, Lk, H, dh, scale, dropout_p, 1.0f / (1.0f - dropout_p), seed, stream_id};
     MEDP_TRY(check(p));
     MEDP_CHECK_ARG(dout && dq && dk && dv, "attn_small_bwd: null gradient buffer");
@@ -231,7 +233,7 @@ extern "C" int medp_attn_small_bwd(const float* dout, int lddo, const float* q, 
     }
     const int nper = (Lk + 63) / 64;
     hipStream_t st = (hipStream_t)stream;
-#define MEDP_BWD_ARGS p, dout, lddo, dq, lddq, dk, lddk, dv, lddv
+#define MEDP_BWD_ARGS p, dout, lddo, dq, lddq, dk, lddk, dv, lddv, dkv_batch_stride
     if (nper <= 1) attn_small_bwd_kernel<1><<<B * H, 256, lds, st>>>(MEDP_BWD_ARGS);
     else if (nper <= 2) attn_small_bwd_kernel<2><<<B * H, 256, lds, st>>>(MEDP_BWD_ARGS);
     else if (nper <= 4) attn_small_bwd_kernel<4><<<B * H, 256, lds, st>>>(MEDP_BWD_ARGS);

@@ -1,0 +1,285 @@
+// DuETT (dual-axis event x time transformer) encode path for gfx950, inference form (BatchNorm folded to an affine):
+//   DuettFeatureExtractor.encode, reference models/main_architecture_duett.py:31-94 (== duett/duett.py:245-280).
+//
+// psi [B, T+1, V+1, E] fp32 is built by ONE launch (the reference runs V sequential 5-op MLPs, ~250 eager launches):
+// a workgroup handles 256 (batch, time) cells of one variable with that variable's MLP weights broadcast from LDS.
+// The layer loop alternates the two token views of psi
+//     event view [B, V+1, (T+1)E]  <->  time view [B, T+1, (V+1)E]
+// through "axis swap + add" kernels that move whole E-float (96 B) cells with 16-B accesses and fuse the positional
+// add and the preceding encoder's final ScaleNorm scaling (per-row 1/||x||), so psi makes one HBM round trip per swap.
+// Each encoder (x_transformers Encoder(depth=1), restated in oracle/xt_encoder.py) is
+//     x += to_out(attn(ScaleNorm(x)));  x += ff2(gelu(ff1(ScaleNorm(x))));  [x = ScaleNorm(x)]
+// with ScaleNorm emitting bf16 straight into the MFMA GEMMs and both residual adds fused in GEMM epilogues.
+#include "common.h"
+#include "medp_hip.h"
+
+namespace {
+
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+inline int grid_for(size_t work_items) { return (int)min((size_t)4096, max((size_t)1, (work_items + 255) / 256)); }
+
+// ---- static (tabular) encoder: Linear(Ds,128) -> ReLU -> BN(eval affine) -> Linear(128,E);  one block per sample ----
+__global__ __launch_bounds__(128) void tab_encoder_kernel(const float* __restrict__ xs, const float* __restrict__ w0,
+                                                          const float* __restrict__ b0, const float* __restrict__ s,
+                                                          const float* __restrict__ sh, const float* __restrict__ w4,
+                                                          const float* __restrict__ b4, float* __restrict__ out, int Ds, int Hd, int E) {
+    extern __shared__ float hid[];
+    const int b = blockIdx.x;
+    for (int j = threadIdx.x; j < Hd; j += blockDim.x) {
+        float a = b0[j];
+        for (int i = 0; i < Ds; ++i) a += w0[j * Ds + i] * xs[(size_t)b * Ds + i];
+        hid[j] = fmaxf(a, 0.f) * s[j] + sh[j];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+        float a = b4[e];
+        for (int j = 0; j < Hd; ++j) a += w4[e * Hd + j] * hid[j];
+        out[(size_t)b * E + e] = a;
+    }
+}
+
+// ---- fused psi build (K2-K5 of SURVEY.md §2.2) -----------------------------------------------------------------------
+// grid (ceil(B*(T+1)/256), V+1); thread = one (b, t) cell of variable slot v = blockIdx.y.  E <= 32, hidden <= 64.
+template <int E, int HD>
+__global__ __launch_bounds__(256) void psi_embed_kernel(const float* __restrict__ xs_ts, const float* __restrict__ w0,
+                                                        const float* __restrict__ b0, const float* __restrict__ bs,
+                                                        const float* __restrict__ bsh, const float* __restrict__ w4,
+                                                        const float* __restrict__ b4, const float* __restrict__ nobs_table,
+                                                        int nobs_rows, const float* __restrict__ tab_out,
+                                                        const float* __restrict__ special, float* __restrict__ psi, int B, int T, int V) {
+    __shared__ float sw0[HD * 2], sb0[HD], ss[HD], ssh[HD], sw4[E * HD], sb4[E];
+    const int v = blockIdx.y;
+    if (v < V) {
+        for (int i = threadIdx.x; i < HD * 2; i += 256) sw0[i] = w0[(size_t)v * HD * 2 + i];
+        for (int i = threadIdx.x; i < HD; i += 256) {
+            sb0[i] = b0[(size_t)v * HD + i];
+            ss[i] = bs[(size_t)v * HD + i];
+            ssh[i] = bsh[(size_t)v * HD + i];
+        }
+        for (int i = threadIdx.x; i < E * HD; i += 256) sw4[i] = w4[(size_t)v * E * HD + i];
+        for (int i = threadIdx.x; i < E; i += 256) sb4[i] = b4[(size_t)v * E + i];
+    }
+    __syncthreads();
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    if (cell >= B * (T + 1)) return;
+    const int b = cell / (T + 1), t = cell % (T + 1);
+    const int F = 2 * V + 1;
+    float out[E];
+    const float* src = nullptr;   // whole-vector overrides
+    if (t == T) {
+        src = special + E;                                   // REP row: special_embeddings[1]         (model :58-60)
+    } else {
+        const float* row = xs_ts + ((size_t)b * T + t) * F;
+        if (row[2 * V] == 1.0f) {
+            src = special;                                   // masked timestep: special_embeddings[0] (model :61-64)
+        } else if (v == V) {
+            src = tab_out + (size_t)b * E;                   // static column                          (model :57)
+        } else {
+            const float cnt = row[V + v];
+            if (cnt == -1.0f) {
+                src = special;                               // masked event (SSL only)                (model :65-66)
+            } else {
+                const int idx = min(max((int)cnt, 0), nobs_rows - 1);          // .to(int).clip(0, 15) (model :41)
+                const float val = row[v], nob = nobs_table[idx];
+#pragma unroll
+                for (int e = 0; e < E; ++e) out[e] = sb4[e];
+#pragma unroll 8
+                for (int j = 0; j < HD; ++j) {
+                    const float h = fmaxf(sw0[2 * j] * val + sw0[2 * j + 1] * nob + sb0[j], 0.f) * ss[j] + ssh[j];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) out[e] += sw4[e * HD + j] * h;
+                }
+            }
+        }
+    }
+    float* dst = psi + (((size_t)b * (T + 1) + t) * (V + 1) + v) * E;
+    if (src) {
+#pragma unroll
+        for (int e = 0; e < E; e += 4) *(float4*)(dst + e) = *(const float4*)(src + e);
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; e += 4) *(float4*)(dst + e) = make_float4(out[e], out[e + 1], out[e + 2], out[e + 3]);
+    }
+}
+
+// ---- time embedding (K6): cve(batch_norm) = Linear(1,h) -> tanh -> BN affine -> Linear(h, tt) ; REP row appended ------
+__global__ __launch_bounds__(256) void time_embed_kernel(const float* __restrict__ times, const float* __restrict__ w0,
+                                                         const float* __restrict__ b0, const float* __restrict__ s,
+                                                         const float* __restrict__ sh, const float* __restrict__ w3,
+                                                         const float* __restrict__ b3, const float* __restrict__ rep,
+                                                         float* __restrict__ out, int B, int T, int Hd, int tt) {
+    extern __shared__ float hid[];
+    const int row = blockIdx.x;                 // b*(T+1) + t
+    const int b = row / (T + 1), t = row % (T + 1);
+    float* o = out + (size_t)row * tt;
+    if (t == T) {
+        for (int c = threadIdx.x; c < tt; c += 256) o[c] = rep[c];
+        return;
+    }
+    const float tv = times[(size_t)b * T + t];
+    for (int j = threadIdx.x; j < Hd; j += 256) hid[j] = tanhf(w0[j] * tv + b0[j]) * s[j] + sh[j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < tt; c += 256) {
+        float a = b3[c];
+        const float* wr = w3 + (size_t)c * Hd;
+        for (int j = 0; j < Hd; ++j) a += wr[j] * hid[j];
+        o[c] = a;
+    }
+}
+
+// ---- axis swaps (K7): cells of E floats move between [B, A1, A2, E] and [B, A2, A1, E] ------------------------------------
+// out[b][a2][a1][:] = in[b][a1][a2][:] * rowscale(b, a1) + add        add: either per-(a2,a1,e) table (event embedding,
+// batch-invariant, add_bs = 0) or per-(b,a2,a1,e) tensor (time embedding, add_bs = A2*A1*E).  rowscale = rnorm * gain
+// applies the producing encoder's final ScaleNorm (row = one (b, a1) token of A2*E features); rnorm == nullptr -> 1.
+__global__ __launch_bounds__(256) void axis_swap_add_kernel(const float* __restrict__ in, const float* __restrict__ rnorm,
+                                                            const float* __restrict__ g, float gain_sqrt_dim,
+                                                            const float* __restrict__ add, long long add_bs,
+                                                            float* __restrict__ out, int B, int A1, int A2, int E4) {
+    const size_t total = (size_t)B * A1 * A2 * E4;
+    const float gain = rnorm ? gain_sqrt_dim * g[0] : 1.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        // iterate in OUTPUT order (coalesced writes): i = ((b*A2 + a2)*A1 + a1)*E4 + e4
+        const int e4 = (int)(i % E4);
+        size_t r = i / E4;
+        const int a1 = (int)(r % A1);
+        r /= A1;
+        const int a2 = (int)(r % A2);
+        const int b = (int)(r / A2);
+        const float4 v = *(const float4*)(in + ((((size_t)b * A1 + a1) * A2 + a2) * E4 + e4) * 4);
+        const float sc = rnorm ? rnorm[(size_t)b * A1 + a1] * gain : 1.f;
+        const float4 ad = *(const float4*)(add + (size_t)b * add_bs + (((size_t)a2 * A1 + a1) * E4 + e4) * 4);
+        *(float4*)(out + i * 4) = make_float4(v.x * sc + ad.x, v.y * sc + ad.y, v.z * sc + ad.z, v.w * sc + ad.w);
+    }
+}
+
+struct DuettWs {
+    size_t tab, psi, xe, xt, temb, h, qkv, o, f, rn, total;
+};
+DuettWs plan(const MedpDuettWeights* w, int B, int T) {
+    const size_t V1 = w->n_vars + 1, T1 = T + 1, E = w->d_embedding;
+    const size_t cells = (size_t)B * T1 * V1 * E;
+    const size_t rows = (size_t)B * max(T1, V1);
+    DuettWs s{};
+    size_t off = 0;
+    s.tab = off;  off += al((size_t)B * E * 4);
+    s.psi = off;  off += al(cells * 4);
+    s.xe = off;   off += al(cells * 4);
+    s.xt = off;   off += al(cells * 4);
+    s.temb = off; off += al(cells * 4);
+    s.h = off;    off += al(cells * 2);
+    s.qkv = off;  off += al(rows * 3 * E * 4);
+    s.o = off;    off += al(rows * E * 2);
+    s.f = off;    off += al(rows * (size_t)w->d_ff * 2);
+    s.rn = off;   off += al(rows * 4);
+    s.total = off;
+    return s;
+}
+
+// one x_transformers encoder block on x [M = B*N tokens, D] (in place); leaves the FINAL ScaleNorm to the caller
+int encoder_forward(const MedpEncoderWeights& e, const MedpDuettWeights* w, float* x, int B, int N, int D, char* base,
+                    const DuettWs& ws, void* stream) {
+    const int M = B * N, E = w->d_embedding, H = w->n_heads, dh = E / H;
+    void* h = base + ws.h;
+    float* qkv = (float*)(base + ws.qkv);
+    void* o = base + ws.o;
+    void* f = base + ws.f;
+    MEDP_TRY(medp_scalenorm_fwd(x, D, e.g_attn, h, D, 1, nullptr, M, D, w->norm_eps, stream));
+    MEDP_TRY(medp_gemm_bf16_nt(h, e.qkv_w, qkv, M, 3 * E, D, D, D, 3 * E, nullptr, nullptr, nullptr, 0, 0, 0, stream));
+    MEDP_TRY(medp_attn_small_fwd(qkv, 3 * E, (long long)N * 3 * E, qkv + E, qkv + 2 * E, 3 * E, (long long)N * 3 * E, o, E, 1, nullptr,
+                                 B, N, N, H, dh, 1.0f / sqrtf((float)dh), 0.f, 0u, 0u, stream));
+    MEDP_TRY(medp_gemm_bf16_nt(o, e.out_w, x, M, D, E, E, E, D, nullptr, nullptr, x, D, 0, 0, stream));
+    MEDP_TRY(medp_scalenorm_fwd(x, D, e.g_ff, h, D, 1, nullptr, M, D, w->norm_eps, stream));
+    MEDP_TRY(medp_gemm_bf16_nt(h, e.ff1_w, f, M, w->d_ff, D, D, D, w->d_ff, e.ff1_b, nullptr, nullptr, 0, 1, 1, stream));
+    MEDP_TRY(medp_gemm_bf16_nt(f, e.ff2_w, x, M, D, w->d_ff, w->d_ff, w->d_ff, D, e.ff2_b, nullptr, x, D, 0, 0, stream));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t medp_duett_workspace_bytes(const MedpDuettWeights* w, int B, int T) {
+    if (!w || B <= 0 || T <= 0) return 0;
+    return plan(w, B, T).total;
+}
+
+extern "C" int medp_duett_encode(const MedpDuettWeights* w, const float* xs_static, const float* xs_ts, const float* xs_times,
+                                 int B, int T, float* tokens_f32, void* tokens_bf16, float* psi0_out, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    MEDP_CHECK_ARG(w && xs_static && xs_ts && xs_times && workspace, "duett_encode: null argument");
+    MEDP_CHECK_ARG(tokens_f32, "duett_encode: tokens_f32 output is required");
+    MEDP_CHECK_ARG(B > 0 && T > 0, "duett_encode: bad shape B=%d T=%d", B, T);
+    MEDP_CHECK_ARG(w->d_embedding == 24 && w->d_hidden_embed == 64, "duett_encode: built for d_embedding 24 / hidden 64 (duett.py:50)");
+    MEDP_CHECK_ARG(w->d_embedding % w->n_heads == 0 && (3 * w->d_embedding) % 4 == 0, "duett_encode: bad head split");
+    const DuettWs ws = plan(w, B, T);
+    MEDP_CHECK_ARG(workspace_bytes >= ws.total, "duett_encode: workspace %zu < required %zu", workspace_bytes, ws.total);
+    hipStream_t s = (hipStream_t)stream;
+    char* base = (char*)workspace;
+    const int V = w->n_vars, V1 = V + 1, T1 = T + 1, E = w->d_embedding;
+    const int et = E * T1, tt = E * V1;
+    float* tab = (float*)(base + ws.tab);
+    float* psi = (float*)(base + ws.psi);
+    float* xe = (float*)(base + ws.xe);
+    float* xt = (float*)(base + ws.xt);
+    float* temb = (float*)(base + ws.temb);
+    float* rn = (float*)(base + ws.rn);
+
+    tab_encoder_kernel<<<B, 128, w->d_hidden_tab * sizeof(float), s>>>(xs_static, (const float*)w->tab_w0, (const float*)w->tab_b0,
+                                                                       (const float*)w->tab_bn_scale, (const float*)w->tab_bn_shift,
+                                                                       (const float*)w->tab_w4, (const float*)w->tab_b4, tab,
+                                                                       w->n_static, w->d_hidden_tab, E);
+    MEDP_LAUNCH_CHECK("duett tab_encoder");
+    psi_embed_kernel<24, 64><<<dim3((B * T1 + 255) / 256, V1), 256, 0, s>>>(
+        xs_ts, (const float*)w->emb_w0, (const float*)w->emb_b0, (const float*)w->emb_bn_scale, (const float*)w->emb_bn_shift,
+        (const float*)w->emb_w4, (const float*)w->emb_b4, (const float*)w->n_obs_table, w->n_obs_rows, tab, (const float*)w->special, psi,
+        B, T, V);
+    MEDP_LAUNCH_CHECK("duett psi_embed");
+    if (psi0_out) {
+        hipError_t e = hipMemcpyAsync(psi0_out, psi, (size_t)B * T1 * V1 * E * 4, hipMemcpyDeviceToDevice, s);
+        MEDP_CHECK_ARG(e == hipSuccess, "duett_encode: psi0 copy failed");
+    }
+    time_embed_kernel<<<B * T1, 256, w->d_hidden_time * sizeof(float), s>>>(
+        xs_times, (const float*)w->time_w0, (const float*)w->time_b0, (const float*)w->time_bn_scale, (const float*)w->time_bn_shift,
+        (const float*)w->time_w3, (const float*)w->time_b3, (const float*)w->rep_embedding, temb, B, T, w->d_hidden_time, tt);
+    MEDP_LAUNCH_CHECK("duett time_embed");
+
+    const int E4 = E / 4;
+    const int swap_grid = grid_for((size_t)B * T1 * V1 * E4);
+    const float* cur = psi;          // time view [B, T1, V1, E]; rows (b,t) of tt features
+    const float* cur_rn = nullptr;   // pending final-ScaleNorm row scales of `cur`
+    const float* cur_g = nullptr;
+    for (int l = 0; l < w->n_layers; ++l) {
+        // time view -> event view (+ event embedding), applying the previous time encoder's final norm      (model :80)
+        axis_swap_add_kernel<<<swap_grid, 256, 0, s>>>(cur, cur_rn, cur_g, sqrtf((float)tt), (const float*)w->event_embedding, 0, xe, B, T1,
+                                                       V1, E4);
+        MEDP_LAUNCH_CHECK("duett swap t->e");
+        MEDP_TRY(encoder_forward(w->event_enc[l], w, xe, B, V1, et, base, ws, stream));                      // (model :81)
+        const float* e_rn = nullptr;
+        if (w->final_norm) {
+            // final ScaleNorm of the event encoder: statistics now, scaling fused into the swap below
+            MEDP_TRY(medp_scalenorm_fwd(xe, et, w->event_enc[l].g_final, base + ws.h, et, 1, rn, B * V1, et, w->norm_eps, stream));
+            e_rn = rn;
+        }
+        // event view -> time view (+ time embedding)                                                          (model :81,:90)
+        axis_swap_add_kernel<<<swap_grid, 256, 0, s>>>(xe, e_rn, (const float*)w->event_enc[l].g_final, sqrtf((float)et), temb,
+                                                       (long long)T1 * V1 * E, xt, B, V1, T1, E4);
+        MEDP_LAUNCH_CHECK("duett swap e->t");
+        MEDP_TRY(encoder_forward(w->time_enc[l], w, xt, B, T1, tt, base, ws, stream));                        // (model :91)
+        if (l + 1 < w->n_layers) {
+            if (w->final_norm) {
+                MEDP_TRY(medp_scalenorm_fwd(xt, tt, w->time_enc[l].g_final, base + ws.h, tt, 1, rn, B * T1, tt, w->norm_eps, stream));
+                cur_rn = rn;
+                cur_g = (const float*)w->time_enc[l].g_final;
+            }
+            // ping-pong: the next swap reads xt and writes xe
+            cur = xt;
+        } else {
+            if (w->final_norm) {
+                MEDP_TRY(medp_scalenorm_fwd(xt, tt, w->time_enc[l].g_final, tokens_f32, tt, 0, nullptr, B * T1, tt, w->norm_eps, stream));
+            } else {
+                hipError_t e = hipMemcpyAsync(tokens_f32, xt, (size_t)B * T1 * tt * 4, hipMemcpyDeviceToDevice, s);
+                MEDP_CHECK_ARG(e == hipSuccess, "duett_encode: output copy failed");
+            }
+        }
+    }
+    if (tokens_bf16) MEDP_TRY(medp_cast_f32_bf16(tokens_f32, tt, tokens_bf16, tt, B * T1, tt, stream));
+    return 0;
+}

@@ -152,7 +152,7 @@ extern "C" int medp_gelu_bwd(const float* dy, const float* pre, float* dx, long 
 
 extern "C" int medp_im2col_patch(const float* pix, void* A, int B, int C, int H, int W, int patch, int kpad, void* stream) {
     MEDP_CHECK_ARG(pix && A && B > 0 && C > 0 && patch > 0, "im2col: bad argument");
-    MEDP_CHECK_ARG(H % patch == 0 && W % patch == 0, "im2col: image %dx%d is not a multiple of the patch size %d", H, W, patch);
+    MEDP_CHECK_ARG(H >= patch && W >= patch, "im2col: image %dx%d smaller than the patch size %d", H, W, patch);   /* conv stride semantics: the remainder rows/cols are ignored */
     MEDP_CHECK_ARG(kpad >= C * patch * patch && kpad % 8 == 0, "im2col: kpad must be >= C*p*p and a multiple of 8");
     const size_t total = (size_t)B * (H / patch) * (W / patch) * kpad;
     im2col_patch_kernel<<<grid_for(total), 256, 0, (hipStream_t)stream>>>(pix, (bf16_t*)A, B, C, H, W, patch, kpad);

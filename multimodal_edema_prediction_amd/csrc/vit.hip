@@ -39,7 +39,7 @@ extern "C" int medp_vit_forward(const MedpVitWeights* w, const float* pixels, in
     MEDP_CHECK_ARG(w && pixels && workspace, "vit_forward: null argument");
     MEDP_CHECK_ARG(tokens_f32 || tokens_bf16, "vit_forward: no output requested");
     MEDP_CHECK_ARG(w->hidden == w->n_heads * 64, "vit_forward: head dim must be 64 (hidden %d, heads %d)", w->hidden, w->n_heads);
-    MEDP_CHECK_ARG(H % w->patch == 0 && W % w->patch == 0, "vit_forward: image %dx%d not a multiple of patch %d", H, W, w->patch);
+    MEDP_CHECK_ARG(H >= w->patch && W >= w->patch, "vit_forward: image %dx%d smaller than one patch (%d)", H, W, w->patch);
     const VitWs ws = plan(w, B, H, W);
     MEDP_CHECK_ARG(workspace_bytes >= ws.total, "vit_forward: workspace %zu < required %zu", workspace_bytes, ws.total);
     char* base = (char*)workspace;

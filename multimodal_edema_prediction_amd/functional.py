@@ -133,18 +133,23 @@ def attn_small_fwd(q, k, v, B, Lq, Lk, H, dh, scale, *, q_batch_stride=None, kv_
 
 
 def attn_small_bwd(dout, q, k, v, B, Lq, Lk, H, dh, scale, *, q_batch_stride=None, kv_batch_stride=None, dropout_p=0.0,
-                   seed=0, stream_id=0):
+                   seed=0, stream_id=0, dkv_out=None):
+    """Returns (dq [B,Lq,D], dk, dv).  dk/dv are the two column halves of one [B, Lk, 2D] buffer (`dkv_out`, which may be a
+    strided view, e.g. rows 1.. of a [B, Lk+1, 2D] tensor) so the fused K|V projection gets its gradient without a concat."""
     ldq, ldkv = q.stride(-2), k.stride(-2)
     qbs = Lq * ldq if q_batch_stride is None else q_batch_stride
     kbs = Lk * ldkv if kv_batch_stride is None else kv_batch_stride
     D = H * dh
     dq = torch.empty((B, Lq, D), dtype=F32, device=k.device)
-    dk = torch.empty((B, Lk, D), dtype=F32, device=k.device)
-    dv = torch.empty((B, Lk, D), dtype=F32, device=k.device)
+    if dkv_out is None:
+        dkv_out = torch.empty((B, Lk, 2 * D), dtype=F32, device=k.device)
+    assert dkv_out.stride(-1) == 1 and dkv_out.shape[-1] == 2 * D
     d2 = dout.reshape(B * Lq, D)
-    check(lib().medp_attn_small_bwd(ptr(d2), _ld(d2), ptr(q), ldq, qbs, ptr(k), ptr(v), ldkv, kbs, ptr(dq), D, ptr(dk), D, ptr(dv),
-                                     D, B, Lq, Lk, H, dh, scale, dropout_p, seed, stream_id, stream()), "attn_small_bwd")
-    return dq, dk, dv
+    base = dkv_out.data_ptr()
+    check(lib().medp_attn_small_bwd(ptr(d2), _ld(d2), ptr(q), ldq, qbs, ptr(k), ptr(v), ldkv, kbs, ptr(dq), D, base,
+                                     dkv_out.stride(-2), base + 4 * D, 0, dkv_out.stride(0), B, Lq, Lk, H, dh, scale, dropout_p,
+                                     seed, stream_id, stream()), "attn_small_bwd")
+    return dq, dkv_out[..., :D], dkv_out[..., D:]
 
 
 def gelu_bwd(dy: torch.Tensor, pre: torch.Tensor) -> torch.Tensor:

@@ -1,0 +1,253 @@
+"""Host-side mirror of the reference's `models/main_architecture_duett.py` (live classes only):
+`DuettFeatureExtractor`, `load_duett_backbone`, `CXREncoder`, `PatchDualPathologyPerceiver`, `_PerceiverBlock`,
+`TeacherModel`, `StudentModel` — same names, constructor signatures, attribute / parameter names, output dict keys and
+error behaviour, so `training_duett/{engine,trainer,evaluator}.py` run against it unchanged
+(INTEGRATION.md shows the two-line module alias).  torch layers are parameter containers (identical state_dict keys and
+default initialisation order); all arithmetic is HIP through `autograd_ops` / the whole-module C calls.
+
+`TemporalPerceiver`, `PathologyPerceiver`, `DualPathologyPerceiver` are commented out in the reference at HEAD
+(model file :176-535, :659-741) and are deliberately absent here too: the reference trainer soft-imports them to None.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import autograd_ops as A
+from . import functional as Fn
+from .cxr import CXREncoder, Dinov2Cfg  # noqa: F401  (re-exported)
+from .duett import DuettFeatureExtractor, load_duett_backbone  # noqa: F401  (re-exported)
+
+__all__ = ["DuettFeatureExtractor", "load_duett_backbone", "CXREncoder", "PatchDualPathologyPerceiver", "_PerceiverBlock",
+           "TeacherModel", "StudentModel"]
+
+# dropout stream ids (one per dropout site; combined with a per-forward seed)
+_SID = {"img_cross": 0, "img_self": 10, "ts_cross": 20, "ts_self": 30, "image_head": 40, "temporal_head": 41,
+        "correction_head": 42, "student_head": 50}
+
+
+class _BroadcastRowsFn(torch.autograd.Function):
+    """[L, D] -> [B, L, D] (the shared pathology queries, model :602-603); backward sums over the batch with the HIP column sum."""
+
+    @staticmethod
+    def forward(ctx, x, B):
+        ctx.B = B
+        return x.unsqueeze(0).expand(B, -1, -1).contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        L, D = dy.shape[1], dy.shape[2]
+        return Fn.colsum(dy.contiguous().view(ctx.B, L * D)).view(L, D), None
+
+
+class _PerceiverBlock(nn.Module):
+    """Mirror of model file :745-774."""
+    _DEBUG_NORMS: bool = False
+
+    def __init__(self, d: int, n_heads: int, dropout: float):
+        super().__init__()
+        self.norm_q = nn.LayerNorm(d)
+        self.norm_kv = nn.LayerNorm(d)
+        self.attn = nn.MultiheadAttention(d, n_heads, dropout=dropout, batch_first=True)
+        self.norm_ff = nn.LayerNorm(d)
+        self.ff = nn.Sequential(nn.Linear(d, d * 4), nn.GELU(), nn.Dropout(dropout), nn.Linear(d * 4, d), nn.Dropout(dropout))
+        self._sid = 0
+
+    def forward(self, latents, kv, return_attn: bool = False, *, _kv_skip: int = 0, _shared_q: Optional[torch.Tensor] = None,
+                _self_attn: bool = False, _seed: Optional[int] = None):
+        """latents [B, L, d]; kv [B, N(+skip), d].  `_shared_q` ([L, d]) marks latents as the batch-broadcast pathology
+        queries so that norm_q / the Q projection run once instead of B times (identical values)."""
+        d = latents.shape[-1]
+        H = self.attn.num_heads
+        p_attn = float(self.attn.dropout) if self.training else 0.0
+        p_ff = float(self.ff[2].p) if self.training else 0.0
+        p_ff2 = float(self.ff[4].p) if self.training else 0.0
+        seed = (A.next_seed() if _seed is None else _seed) if (p_attn > 0 or p_ff > 0 or p_ff2 > 0) else 0
+        W, b = self.attn.in_proj_weight, self.attn.in_proj_bias
+        q_src = _shared_q if _shared_q is not None else latents
+        qn = A.layer_norm(q_src, self.norm_q.weight, self.norm_q.bias, self.norm_q.eps)
+        Q = A.linear(qn, W[:d], b[:d])
+        kn = A.layer_norm(kv, self.norm_kv.weight, self.norm_kv.bias, self.norm_kv.eps)
+        KV = A.linear(kn, W[d:], b[d:])
+        o, attn_w = A.attn_small(Q, KV, H, (d // H) ** -0.5, p_attn, seed, self._sid, _kv_skip, return_attn)
+        latents = A.linear(o, self.attn.out_proj.weight, self.attn.out_proj.bias, residual=latents)
+        h = A.layer_norm(latents, self.norm_ff.weight, self.norm_ff.bias, self.norm_ff.eps)
+        h = A.linear(h, self.ff[0].weight, self.ff[0].bias)
+        h = A.gelu_dropout(h, p_ff, seed, self._sid + 1)
+        if p_ff2 > 0:
+            y = A.linear(h, self.ff[3].weight, self.ff[3].bias)
+            latents = A.dropout_add(y, latents, p_ff2, seed, self._sid + 2)
+        else:
+            latents = A.linear(h, self.ff[3].weight, self.ff[3].bias, residual=latents)
+        if return_attn:
+            return latents, attn_w
+        return latents
+
+
+class PatchDualPathologyPerceiver(nn.Module):
+    """Mirror of model file :538-654 (construction order preserved: same default initialisation under a fixed seed)."""
+
+    def __init__(self, n_pathologies: int, d_ts: int, d_latent: int = 256, n_heads: int = 4, dropout: float = 0.1,
+                 head_hidden: int = 64, head_dropout: float = 0.1):
+        super().__init__()
+        self.n_pathologies = n_pathologies
+        self.d_latent = d_latent
+        self.d_ts = d_ts
+        self.shared_queries = nn.Parameter(torch.randn(n_pathologies, d_latent) * 0.02)
+        self.ts_proj = nn.Linear(d_ts, d_latent)
+        self.img_cross = _PerceiverBlock(d_latent, n_heads, dropout)
+        self.img_self = _PerceiverBlock(d_latent, n_heads, dropout)
+        self.ts_cross = _PerceiverBlock(d_latent, n_heads, dropout)
+        self.ts_self = _PerceiverBlock(d_latent, n_heads, dropout)
+        for name in ("img_cross", "img_self", "ts_cross", "ts_self"):
+            getattr(self, name)._sid = _SID[name]
+
+        def _mk_head():
+            return nn.Sequential(nn.Linear(d_latent, head_hidden), nn.GELU(), nn.Dropout(head_dropout), nn.Linear(head_hidden, 1))
+
+        self.image_head = _mk_head()
+        self.temporal_head = _mk_head()
+        self.correction_head = nn.Sequential(nn.LayerNorm(d_latent), nn.Linear(d_latent, head_hidden), nn.GELU(),
+                                             nn.Dropout(head_dropout), nn.Linear(head_hidden, 1, bias=False))
+        nn.init.zeros_(self.correction_head[-1].weight)
+        self.beta = nn.Parameter(torch.ones(n_pathologies))
+        self.image_label_bias = nn.Parameter(torch.zeros(n_pathologies))
+        self.temporal_label_bias = nn.Parameter(torch.zeros(n_pathologies))
+
+    def _head(self, x, seq, seed, sid):
+        """Linear(d,h) -> GELU -> Dropout -> Linear(h,1)   (model :572-575)"""
+        p = float(seq[2].p) if seq[2].training else 0.0
+        h = A.linear(x, seq[0].weight, seq[0].bias)
+        h = A.gelu_dropout(h, p, seed, sid)
+        return A.rowdot(h, seq[3].weight, seq[3].bias)
+
+    def forward(self, ts_tokens, img_patches_proj, return_attn=False, ts_ablation="hourly_only", *, _img_skip: int = 0):
+        if ts_tokens.ndim != 3:
+            raise ValueError(f"ts_tokens must be [B, T+1, d_ts], got {tuple(ts_tokens.shape)}")
+        B = ts_tokens.size(0)
+        if ts_ablation == "full":
+            ts_selected = ts_tokens
+        elif ts_ablation == "hourly_only":
+            ts_selected = ts_tokens[:, :-1, :]
+        elif ts_ablation == "rep_only":
+            ts_selected = ts_tokens[:, -1:, :]
+        else:
+            raise ValueError(f"unknown ts_ablation={ts_ablation!r}; expected one of "
+                             "{'full', 'hourly_only', 'rep_only'}")
+        seed = A.next_seed() if self.training else 0
+        q0 = _BroadcastRowsFn.apply(self.shared_queries, B)             # img_q == ts_q (model :602-603)
+        ts_kv = A.linear(ts_selected, self.ts_proj.weight, self.ts_proj.bias)
+
+        I, img_attn = self.img_cross(q0, img_patches_proj, True, _kv_skip=_img_skip, _shared_q=self.shared_queries, _seed=seed) \
+            if return_attn else (self.img_cross(q0, img_patches_proj, _kv_skip=_img_skip, _shared_q=self.shared_queries, _seed=seed), None)
+        I = self.img_self(I, I, _seed=seed)
+        T_tok, ts_attn = self.ts_cross(q0, ts_kv, True, _shared_q=self.shared_queries, _seed=seed) \
+            if return_attn else (self.ts_cross(q0, ts_kv, _shared_q=self.shared_queries, _seed=seed), None)
+        T_tok = self.ts_self(T_tok, T_tok, _seed=seed)
+
+        hi = self._head(I, self.image_head, seed, _SID["image_head"])
+        ht = self._head(T_tok, self.temporal_head, seed, _SID["temporal_head"])
+        ch = self.correction_head
+        c = A.layer_norm(T_tok, ch[0].weight, ch[0].bias, ch[0].eps)
+        c = A.linear(c, ch[1].weight, ch[1].bias)
+        c = A.gelu_dropout(c, float(ch[3].p) if ch[3].training else 0.0, seed, _SID["correction_head"])
+        ts_correction = A.rowdot(c, ch[4].weight, None)
+        img_logits, ts_logits, scaled_correction, fusion_logits = A.FusionLogitsFn.apply(
+            hi, ht, ts_correction, self.image_label_bias, self.temporal_label_bias, self.beta)
+        out = {"img_logits": img_logits, "ts_logits": ts_logits, "fusion_logits": fusion_logits, "img_tokens": I,
+               "ts_tokens": T_tok, "fusion_tokens": T_tok, "ts_correction": ts_correction,
+               "scaled_correction": scaled_correction}
+        if return_attn:
+            out["img_attn"] = img_attn
+            out["ts_attn"] = ts_attn
+        return out
+
+
+class TeacherModel(nn.Module):
+    """Mirror of model file :993-1197.  The live configuration (`patch_dual_pathology_mode=True`, run_duett.sh:8) is built;
+    the other modes need perceiver classes that are commented out in the reference and raise here."""
+
+    def __init__(self, duett_backbone: DuettFeatureExtractor, cxr_encoder: CXREncoder, perceiver, head_hidden: int = 128,
+                 head_dropout: float = 0.1, cxr_return_patches: bool = True, d_img: int = 768, use_aux_cxr: bool = True,
+                 aux_head_hidden: int = 128, pathology_mode: bool = False, dual_pathology_mode: bool = False,
+                 patch_dual_pathology_mode: bool = False, pretrained_cxr_head_ckpt: Optional[str] = None,
+                 pathology_labels: Optional[tuple] = None):
+        super().__init__()
+        n_modes = sum([pathology_mode, dual_pathology_mode, patch_dual_pathology_mode])
+        if n_modes > 1:
+            raise ValueError("pathology_mode / dual_pathology_mode / patch_dual_pathology_mode: at most one may be True")
+        self.duett = duett_backbone
+        self.cxr = cxr_encoder
+        self.perceiver = perceiver
+        self.cxr_return_patches = cxr_return_patches
+        self.pathology_mode = pathology_mode
+        self.dual_pathology_mode = dual_pathology_mode
+        self.patch_dual_pathology_mode = patch_dual_pathology_mode
+        d = perceiver.d_latent
+        self.img_proj = nn.Linear(d_img, d)
+        if pathology_mode or dual_pathology_mode or patch_dual_pathology_mode:
+            self.head = None
+            self.aux_cxr_head = None
+            self.use_aux_cxr = False
+        else:
+            self.head = nn.Sequential(nn.Linear(d, head_hidden), nn.GELU(), nn.Dropout(head_dropout), nn.Linear(head_hidden, 1))
+            self.use_aux_cxr = use_aux_cxr
+            if use_aux_cxr:
+                self.aux_cxr_head = nn.Sequential(nn.Linear(d, aux_head_hidden), nn.GELU(), nn.Dropout(head_dropout),
+                                                  nn.Linear(aux_head_hidden, 1))
+        if dual_pathology_mode:
+            if pretrained_cxr_head_ckpt is None or pathology_labels is None:
+                raise ValueError("dual_pathology_mode requires pretrained_cxr_head_ckpt AND pathology_labels")
+            raise NotImplementedError("dual_pathology_mode needs DualPathologyPerceiver, which is commented out in the reference "
+                                      "at HEAD (model file :659-741); SURVEY.md §8f-2")
+
+    def forward(self, x_ts_list, x_static_list, bin_ends_list, pixel_values: torch.Tensor, batch_size: Optional[int] = None,
+                return_attn: bool = False):
+        if batch_size is None:
+            batch_size = pixel_values.shape[0]
+        x = (x_ts_list, x_static_list, bin_ends_list)
+        duett_in = self.duett.feats_to_input(x, batch_size)
+        ts_tokens = self.duett.encode(duett_in)                             # [B, T+1, D]
+        if not self.patch_dual_pathology_mode:
+            raise NotImplementedError("only patch_dual_pathology_mode is live in the reference at HEAD (SURVEY.md F6)")
+        # CXR tokens after the final LayerNorm as bf16 [B, P+1, d_img]; the class row is skipped inside the cross-attention
+        tokens16 = self.cxr.forward_bf16(pixel_values)
+        img_proj_full = A.linear(tokens16, self.img_proj.weight, self.img_proj.bias)   # [B, P+1, d]
+        out = self.perceiver(ts_tokens, img_proj_full, return_attn=return_attn, _img_skip=1)
+        result = {"main_logit": out["fusion_logits"][:, 0], "img_logits": out["img_logits"], "ts_logits": out["ts_logits"],
+                  "fusion_logits": out["fusion_logits"], "ts_correction": out["ts_correction"],
+                  "scaled_correction": out["scaled_correction"]}
+        if return_attn:
+            for k in ("img_tokens", "ts_tokens", "fusion_tokens", "img_attn", "ts_attn"):
+                result[k] = out[k]
+        return result
+
+
+class StudentModel(nn.Module):
+    """Mirror of model file :1202-1235: DuETT(TS) + MLP head, backbone trained end-to-end."""
+
+    def __init__(self, duett_backbone: DuettFeatureExtractor, pool: str = "mean", head_hidden: int = 128, head_dropout: float = 0.1):
+        super().__init__()
+        self.duett = duett_backbone
+        self.pool = pool
+        d_rep = duett_backbone.d_representation
+        self.head = nn.Sequential(nn.Linear(d_rep, head_hidden), nn.GELU(), nn.Dropout(head_dropout), nn.Linear(head_hidden, 1))
+
+    def forward(self, x_ts_list, x_static_list, bin_ends_list, batch_size: Optional[int] = None) -> torch.Tensor:
+        if batch_size is None:
+            batch_size = len(x_ts_list)
+        x = (x_ts_list, x_static_list, bin_ends_list)
+        duett_in = self.duett.feats_to_input(x, batch_size)
+        ts_tokens = self.duett.encode(duett_in)                             # [B, T+1, d_rep]
+        if self.pool == "rep_token":
+            feat = ts_tokens[:, -1, :]
+        elif self.pool == "mean":
+            feat = A.MeanPoolFn.apply(ts_tokens, ts_tokens.shape[1] - 1)    # REP token excluded
+        else:
+            raise ValueError(f"unknown pool: {self.pool}")
+        p = float(self.head[2].p) if self.training else 0.0
+        h = A.linear(feat, self.head[0].weight, self.head[0].bias)
+        h = A.gelu_dropout(h, p, A.next_seed() if p > 0 else 0, _SID["student_head"])
+        return A.rowdot(h, self.head[3].weight, self.head[3].bias)
