@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Headline benchmark: multimodal TEACHER training-step throughput (BASELINE.json configs[2]: full `dual_patch` teacher,
+CXR 224x224 through a frozen ViT-B/14 + frozen DuETT over T=96 / V=48 vitals + trainable pathology-query fusion head,
+batch 64 per GPU, DualPathologyLoss, AdamW with the reference's LR groups and warm-up/cosine schedule).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+One step = `train_teacher_dual_pathology_batch` (forward of both encoders and the fusion head, loss, backward of every
+trainable parameter, gradient all-reduce when N>1, optimiser step, scheduler step) on one batch already resident in HBM.
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (live HIP-event timing of the dominant kernel,
+the CXR-encoder block GEMMs) and `cpu_baseline` (the CPU oracle timed on the host cores, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+GFLOP_PER_SAMPLE = 48.25           # ViT 46.32 + DuETT fwd 1.04 + 3 x fusion 0.294
+
+
+def build_teacher(T, V, DS, K, device, seed=0):
+    from multimodal_edema_prediction_amd.main_architecture_duett import (CXREncoder, PatchDualPathologyPerceiver, TeacherModel,
+                                                                           load_duett_backbone)
+    torch.manual_seed(seed)
+    backbone = load_duett_backbone("synthetic", d_static_num=DS, d_time_series_num=V, n_timesteps=T, freeze=True)   # --freeze_duett
+    cxr = CXREncoder("synthetic", freeze=True, return_patches=True)
+    perceiver = PatchDualPathologyPerceiver(n_pathologies=K, d_ts=backbone.d_representation, d_latent=256, n_heads=4, dropout=0.2)
+    teacher = TeacherModel(backbone, cxr, perceiver, head_hidden=128, head_dropout=0.2, cxr_return_patches=True, d_img=cxr.d_out,
+                           use_aux_cxr=False, patch_dual_pathology_mode=True)
+    return teacher.to(device)
+
+
+def cpu_baseline(teacher, ccfg, K, batch_cpu, target_seconds=15.0):
+    """The CPU oracle (oracle/step_ref.py) on the host cores, same step, bounded sample."""
+    from oracle import duett_ref, step_ref, vit_ref, optim_ref
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().float().cpu().clone() for k, v in teacher.state_dict().items()}
+    dcfg = duett_ref.DuettCfg(d_static_num=ccfg.d_static, d_time_series_num=ccfg.n_vars, n_timesteps=ccfg.n_timesteps)
+    vcfg = vit_ref.VitCfg()
+    lrs = optim_ref.group_lrs(8e-5)
+    lr_of = lambda name: lrs[optim_ref.param_group_of(name)] * 1e-4
+    state = {"step": 0, "m": {}, "v": {}}
+    n = batch_cpu["y"].shape[0]
+    t0 = time.perf_counter()
+    step_ref.teacher_step(sd, dcfg, vcfg, batch_cpu, state, lr_of)          # warm-up (thread pools, allocator)
+    warm = time.perf_counter() - t0
+    steps = max(1, min(8, int(target_seconds / max(warm, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_ref.teacher_step(sd, dcfg, vcfg, batch_cpu, state, lr_of)
+    dt = time.perf_counter() - t0
+    return {"value": n * steps / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} teacher steps of batch {n} (same shapes: 224x224 CXR, T={ccfg.n_timesteps}, V={ccfg.n_vars}) "
+                      f"through the fp32 CPU oracle, torch.set_num_threads({cores}), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (weak scaling, accelerate semantics)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-batch", action="store_true", help="keep batches on the host: PCIe-inclusive rate (never `value`)")
+    args = ap.parse_args()
+
+    from multimodal_edema_prediction_amd import abi, dp, engine
+    from multimodal_edema_prediction_amd.build import build
+    from multimodal_edema_prediction_amd.cohort import CohortCfg, make_batch
+    from multimodal_edema_prediction_amd.losses_duett import DualPathologyLoss
+    from multimodal_edema_prediction_amd.optim import FusedAdamW, make_param_groups, make_scheduler
+
+    rank, local, world = dp.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if rank == 0:
+        build(verbose=False)
+    if world > 1:
+        torch.distributed.barrier()
+    abi.require_gpu()
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    T, V, DS, K, B = 96, 48, 8, 7, args.batch
+    ccfg = CohortCfg(n_timesteps=T, n_vars=V, d_static=DS, image_size=224, n_labels=K, seed=1234)
+    teacher = build_teacher(T, V, DS, K, device)
+    dp.broadcast_parameters(teacher)
+    loss_fn = DualPathologyLoss(torch.ones(K), None, 0.5, 0.5, 1.0).to(device)
+    opt = FusedAdamW(make_param_groups(teacher, 8e-5), weight_decay=5e-2)
+    sched = make_scheduler(opt, total_steps=max(args.steps + args.warmup, 1000), lr=8e-5)
+    reducer = dp.GradAllReducer([p for p in teacher.parameters() if p.requires_grad]).attach(opt) if world > 1 else None
+
+    # a small pool of distinct synthetic batches; rank r takes items r, r+N, ... of each global batch (§8e)
+    n_pool = 4
+    pool = []
+    for i in range(n_pool):
+        bt = make_batch(ccfg, start=i * B * world + rank, batch_size=B, mode="teacher", stride=world)
+        pool.append(bt if args.host_batch else engine._move_lists(bt, device))
+    torch.cuda.synchronize()
+
+    def step(i):
+        out = engine.train_teacher_dual_pathology_batch(pool[i % n_pool], teacher, loss_fn, opt, device)
+        sched.step()
+        return out
+
+    import warnings
+    warnings.filterwarnings("ignore", message=".*lr_scheduler.step.*")
+    last = None
+    for i in range(args.warmup):
+        last = step(i)
+    L = abi.lib()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    L.medp_gemm_profile_enable(1)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    L.medp_gemm_profile_enable(0) if False else None
+    ms, n_l, fl = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
+    abi.check(L.medp_gemm_profile_collect(ctypes.byref(ms), ctypes.byref(n_l), ctypes.byref(fl)), "gemm_profile_collect")
+    L.medp_gemm_profile_enable(0)
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    value = world * B * args.steps / dt
+    achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("vit_gemm_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    res = {
+        "metric": "multimodal train samples/sec", "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[2]: full multimodal teacher (main_train_teacher_duett, perceiver_type=dual_patch, "
+                               "--freeze_duett, frozen CXR): CXR 224x224 ViT-B/14 + DuETT T=96/F=48, batch 64 per GPU, bf16 MFMA / fp32 "
+                               "accumulate, random-init weights, synthetic cohort seed 1234, perceiver dropout 0.2 ON",
+                   "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                   "gflop_per_sample": GFLOP_PER_SAMPLE, "step_mfma_fraction_of_peak": round(value * GFLOP_PER_SAMPLE / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
+                   "last_loss": round(float(last["loss"]), 5), "batch_location": "host" if args.host_batch else "hbm"},
+        "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel<128,128,1> (CXR-encoder block GEMMs: qkv/proj/fc1/fc2)",
+                     "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                     "traffic": traffic, "launches": int(n_l.value),
+                     "avg_launch_us": round(ms.value * 1e3 / max(n_l.value, 1), 2),
+                     "algorithmic_flops_per_launch": round(fl.value / max(n_l.value, 1), 1)},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        nb = 8
+        cb = make_batch(ccfg, start=10_000, batch_size=nb, mode="teacher")
+        res["cpu_baseline"] = cpu_baseline(teacher, ccfg, K, cb)
+    else:
+        res["cpu_baseline"] = None
+    print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

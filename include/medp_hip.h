@@ -39,6 +39,12 @@ int medp_gemm_bf16_nt(const void* A, const void* W, void* C, int M, int N, int K
                       const float* bias, const float* scale, const float* residual, int ldr, int act, int out_bf16,
                       void* stream);
 
+/* Live timing of the step's dominant kernel (the CXR-encoder block GEMMs launched by medp_vit_forward): when enabled,
+ * HIP events bracket every such launch on its own stream; collect() synchronises the events (host side) and returns the
+ * summed kernel time, the launch count and the algorithmic FLOPs (2*M*N*K per launch).  Used by bench.py's roofline leg. */
+int medp_gemm_profile_enable(int on);
+int medp_gemm_profile_collect(double* host_total_ms, long long* host_n_launches, double* host_total_flops);
+
 /* ---- attention ---------------------------------------------------------------------------------- */
 /* Dense softmax(QK^T*scale)V, head dim 64, bf16 in/out: Dinov2 eager_attention_forward (modeling_dinov2.py:153-178).
  * q/k/v: [B*S, ...] rows with strides ld*, head h at column h*64.  o: [B*S, H*64]. */

@@ -35,6 +35,11 @@ void medp_set_error(const char* fmt, ...);
         if (rc__ != 0) return rc__;  \
     } while (0)
 
+// internal (not part of the C ABI): GEMM launcher with a kernel-symbol tag; tag 1 = CXR-encoder block GEMMs
+int medp_gemm_bf16_nt_tagged(int tag, const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldw, int ldc,
+                             const float* bias, const float* scale, const float* residual, int ldr, int act, int out_bf16,
+                             void* stream);
+
 // ---- bf16 <-> f32 --------------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 // round-to-nearest-even; the plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN a NaN

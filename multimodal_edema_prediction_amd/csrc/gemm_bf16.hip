@@ -17,6 +17,8 @@
 //   * Fused epilogue: + bias[n] -> GELU(erf) -> * scale[n] (LayerScale) -> + residual[m,n] -> fp32 or bf16.
 //   * blockIdx -> tile map is XCD-aware (bijective): the 8 XCDs each get a contiguous run of tiles that
 //     walks N fastest, so one XCD's L2 sees one A row-panel and the whole W.
+#include <vector>
+
 #include "common.h"
 #include "medp_hip.h"
 
@@ -42,7 +44,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN>
+// TAG only gives the CXR-encoder launches their own kernel symbol, so a kernel trace separates the ViT GEMMs (the step's
+// dominant kernel, 4 shapes x 12 layers) from the DuETT / fusion-head launches of the same code.
+template <int BM, int BN, int TAG>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -158,25 +162,63 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const GemmParams p
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int TAG>
 int launch(const GemmParams& p, hipStream_t stream) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     constexpr int LDS = 2 * (BM + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<BM, BN, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    gemm_bf16_nt_kernel<BM, BN><<<tiles, 256, LDS, stream>>>(p);
+    gemm_bf16_nt_kernel<BM, BN, TAG><<<tiles, 256, LDS, stream>>>(p);
     MEDP_LAUNCH_CHECK("medp_gemm_bf16_nt");
     return 0;
 }
 
 }  // namespace
 
-extern "C" int medp_gemm_bf16_nt(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldw,
-                                 int ldc, const float* bias, const float* scale, const float* residual, int ldr,
-                                 int act, int out_bf16, void* stream) {
+// ---- live timing of the dominant kernel (bench.py roofline leg): HIP events around every tag-1 launch, recorded on
+// the stream the kernel is launched on; collected (with a host-side event sync) after the timed region -----------------
+namespace {
+struct GemmProfile {
+    bool on = false;
+    std::vector<hipEvent_t> ev;      // pairs (start, stop)
+    size_t used = 0;
+    double flops = 0.0;
+};
+GemmProfile g_prof;
+}  // namespace
+
+extern "C" int medp_gemm_profile_enable(int on) {
+    g_prof.on = on != 0;
+    g_prof.used = 0;
+    g_prof.flops = 0.0;
+    return 0;
+}
+
+extern "C" int medp_gemm_profile_collect(double* total_ms, long long* n_launches, double* total_flops) {
+    MEDP_CHECK_ARG(total_ms && n_launches && total_flops, "gemm_profile_collect: null argument");
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+        hipError_t e = hipEventSynchronize(g_prof.ev[i + 1]);
+        if (e != hipSuccess) { medp_set_error("gemm_profile_collect: %s", hipGetErrorString(e)); return (int)e; }
+        float t = 0.f;
+        e = hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]);
+        if (e != hipSuccess) { medp_set_error("gemm_profile_collect: %s", hipGetErrorString(e)); return (int)e; }
+        ms += t;
+    }
+    *total_ms = ms;
+    *n_launches = (long long)(g_prof.used / 2);
+    *total_flops = g_prof.flops;
+    g_prof.used = 0;
+    g_prof.flops = 0.0;
+    return 0;
+}
+
+int medp_gemm_bf16_nt_tagged(int tag, const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldw, int ldc,
+                             const float* bias, const float* scale, const float* residual, int ldr, int act, int out_bf16,
+                             void* stream) {
     MEDP_CHECK_ARG(A && W && C, "gemm: null operand");
     MEDP_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
     MEDP_CHECK_ARG(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0, "gemm: K, lda, ldw must be multiples of 8 (16-B chunks)");
@@ -188,6 +230,32 @@ extern "C" int medp_gemm_bf16_nt(const void* A, const void* W, void* C, int M, i
     MEDP_CHECK_ARG(act == 0 || act == 1, "gemm: act must be 0 (none) or 1 (gelu)");
     GemmParams p{(const bf16_t*)A, (const bf16_t*)W, C, M, N, K, lda, ldw, ldc, bias, scale, residual, ldr, act, out_bf16};
     hipStream_t s = (hipStream_t)stream;
-    if (N <= 64) return launch<128, 64>(p, s);
-    return launch<128, 128>(p, s);
+    if (N <= 64) return launch<128, 64, 0>(p, s);
+    if (tag == 1) {
+        const bool prof = g_prof.on;
+        if (prof) {
+            if (g_prof.used + 2 > g_prof.ev.size()) {
+                for (int i = 0; i < 2; ++i) {
+                    hipEvent_t e;
+                    if (hipEventCreate(&e) != hipSuccess) { medp_set_error("gemm profile: hipEventCreate failed"); return 1; }
+                    g_prof.ev.push_back(e);
+                }
+            }
+            hipEventRecord(g_prof.ev[g_prof.used], s);
+        }
+        const int rc = launch<128, 128, 1>(p, s);
+        if (prof) {
+            hipEventRecord(g_prof.ev[g_prof.used + 1], s);
+            g_prof.used += 2;
+            g_prof.flops += 2.0 * (double)M * (double)N * (double)K;
+        }
+        return rc;
+    }
+    return launch<128, 128, 0>(p, s);
+}
+
+extern "C" int medp_gemm_bf16_nt(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldw, int ldc,
+                                 const float* bias, const float* scale, const float* residual, int ldr, int act, int out_bf16,
+                                 void* stream) {
+    return medp_gemm_bf16_nt_tagged(0, A, W, C, M, N, K, lda, ldw, ldc, bias, scale, residual, ldr, act, out_bf16, stream);
 }

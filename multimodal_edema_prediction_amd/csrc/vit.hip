@@ -66,13 +66,13 @@ extern "C" int medp_vit_forward(const MedpVitWeights* w, const float* pixels, in
     for (int l = 0; l < w->n_layers; ++l) {
         const MedpVitLayer& L = w->layers[l];
         MEDP_TRY(medp_layernorm_fwd(x, D, L.ln1_w, L.ln1_b, h, D, 1, nullptr, nullptr, M, D, w->ln_eps, stream));
-        MEDP_TRY(medp_gemm_bf16_nt(h, L.qkv_w, qkv, M, 3 * D, D, D, D, 3 * D, L.qkv_b, nullptr, nullptr, 0, 0, 1, stream));
+        MEDP_TRY(medp_gemm_bf16_nt_tagged(1, h, L.qkv_w, qkv, M, 3 * D, D, D, D, 3 * D, L.qkv_b, nullptr, nullptr, 0, 0, 1, stream));
         MEDP_TRY(medp_attn_fwd_dh64(qkv, (const bf16_t*)qkv + D, (const bf16_t*)qkv + 2 * D, att, B, S, w->n_heads, 3 * D, 3 * D,
                                     3 * D, D, scale, stream));
-        MEDP_TRY(medp_gemm_bf16_nt(att, L.proj_w, x, M, D, D, D, D, D, L.proj_b, L.ls1, x, D, 0, 0, stream));
+        MEDP_TRY(medp_gemm_bf16_nt_tagged(1, att, L.proj_w, x, M, D, D, D, D, D, L.proj_b, L.ls1, x, D, 0, 0, stream));
         MEDP_TRY(medp_layernorm_fwd(x, D, L.ln2_w, L.ln2_b, h, D, 1, nullptr, nullptr, M, D, w->ln_eps, stream));
-        MEDP_TRY(medp_gemm_bf16_nt(h, L.fc1_w, f, M, w->mlp_hidden, D, D, D, w->mlp_hidden, L.fc1_b, nullptr, nullptr, 0, 1, 1, stream));
-        MEDP_TRY(medp_gemm_bf16_nt(f, L.fc2_w, x, M, D, w->mlp_hidden, w->mlp_hidden, w->mlp_hidden, D, L.fc2_b, L.ls2, x, D, 0, 0, stream));
+        MEDP_TRY(medp_gemm_bf16_nt_tagged(1, h, L.fc1_w, f, M, w->mlp_hidden, D, D, D, w->mlp_hidden, L.fc1_b, nullptr, nullptr, 0, 1, 1, stream));
+        MEDP_TRY(medp_gemm_bf16_nt_tagged(1, f, L.fc2_w, x, M, D, w->mlp_hidden, w->mlp_hidden, w->mlp_hidden, D, L.fc2_b, L.ls2, x, D, 0, 0, stream));
     }
     if (tokens_f32)
         MEDP_TRY(medp_layernorm_fwd(x, D, w->final_ln_w, w->final_ln_b, tokens_f32, D, 0, nullptr, nullptr, M, D, w->ln_eps, stream));

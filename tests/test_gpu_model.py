@@ -157,7 +157,7 @@ def test_teacher_engine_step_with_fused_adamw(tbatch):
         if not p.requires_grad:
             continue
         step = (p.detach() - before[k] * (1 - 8e-5 * 5e-2)).abs()
-        assert float(step.max()) <= 8e-5 * 1.001 + 1e-9, k
+        assert float(step.max()) <= 8e-5 + 5e-7, k      # fp32 rounding of the subtraction on O(1) values
         s = float(p.detach().double().abs().sum())
         np.testing.assert_allclose(s, gold["post:" + k][1], rtol=2e-4, atol=2e-3)
         n += 1
