@@ -40,10 +40,23 @@ def build_teacher(T, V, DS, K, device, seed=0):
     return teacher.to(device)
 
 
+def usable_cores() -> int:
+    """Cores this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU box hands a 1-GPU job a
+    16-core share of a 256-thread host; running 256 torch threads on it oversubscribes ~16x)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("MEDP_CPU_CORES", "16"))))
+
+
 def cpu_baseline(teacher, ccfg, K, batch_cpu, target_seconds=15.0):
     """The CPU oracle (oracle/step_ref.py) on the host cores, same step, bounded sample."""
     from oracle import duett_ref, step_ref, vit_ref, optim_ref
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = usable_cores()
     torch.set_num_threads(cores)
     sd = {k: v.detach().float().cpu().clone() for k, v in teacher.state_dict().items()}
     dcfg = duett_ref.DuettCfg(d_static_num=ccfg.d_static, d_time_series_num=ccfg.n_vars, n_timesteps=ccfg.n_timesteps)
@@ -55,7 +68,7 @@ def cpu_baseline(teacher, ccfg, K, batch_cpu, target_seconds=15.0):
     t0 = time.perf_counter()
     step_ref.teacher_step(sd, dcfg, vcfg, batch_cpu, state, lr_of)          # warm-up (thread pools, allocator)
     warm = time.perf_counter() - t0
-    steps = max(1, min(8, int(target_seconds / max(warm, 1e-3))))
+    steps = max(1, min(8, int((target_seconds - warm) / max(warm, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(steps):
         step_ref.teacher_step(sd, dcfg, vcfg, batch_cpu, state, lr_of)
@@ -170,7 +183,7 @@ def main():
                      "algorithmic_flops_per_launch": round(fl.value / max(n_l.value, 1), 1)},
     }
     if world == 1 and not args.no_cpu_baseline:
-        nb = 8
+        nb = 4
         cb = make_batch(ccfg, start=10_000, batch_size=nb, mode="teacher")
         res["cpu_baseline"] = cpu_baseline(teacher, ccfg, K, cb)
     else:
