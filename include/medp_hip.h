@@ -187,6 +187,14 @@ int medp_dual_pathology_loss(const float* img, const float* ts, const float* fus
 int medp_student_kd_loss(const float* z_s, const float* z_t, const float* y, float T, float alpha, float pos_weight, float* out,
                          float* g_zs, int B, void* stream);
 
+/* engine extras: aux residual KL with label smoothing (training_duett/engine.py:149-165); LP regularisers
+ * coef*mean(x^2) (engine.py:217-223); the linear probe's global masked BCE (cxr_linear_training.ipynb:426-437).
+ * Each writes the scalar to out[0] and, when g != NULL, the gradient w.r.t. its differentiable input. */
+int medp_aux_residual_kl(const float* img_logits, const float* scaled_correction, const float* y, const float* mask,
+                         float label_smoothing, float* out, float* g_scaled, int n, void* stream);
+int medp_sq_mean(const float* x, float coef, float* out, float* g, int n, void* stream);
+int medp_masked_bce_global(const float* logits, const float* y, const float* mask, float* out, float* g, int n, void* stream);
+
 /* ---- optimiser: torch.optim.AdamW semantics over a device table of tensors (trainer.py:77-116,383) -------------- */
 typedef struct {
     void* param;            /* fp32, updated in place */

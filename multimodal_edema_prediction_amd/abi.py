@@ -87,6 +87,9 @@ SIGNATURES = {
     "medp_meanpool_bwd": (I, [P, P, I, I, I, I, P]),
     "medp_dual_pathology_loss": (I, [P, P, P, P, P, P, P, F, F, F, F, P, P, P, P, I, I, P]),
     "medp_student_kd_loss": (I, [P, P, P, F, F, F, P, P, I, P]),
+    "medp_aux_residual_kl": (I, [P, P, P, P, F, P, P, I, P]),
+    "medp_sq_mean": (I, [P, F, P, P, I, P]),
+    "medp_masked_bce_global": (I, [P, P, P, P, P, I, P]),
     "medp_adamw_chunk_elems": (I, []),
     "medp_adamw_multi": (I, [P, P, P, I, F, F, F, I, F, P]),
 }

@@ -52,6 +52,17 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, residual):
         xb = x if x.dtype == BF16 else Fn.to_bf16(x.contiguous())
         x2 = xb.reshape(-1, xb.shape[-1])
+        N = weight.shape[0]
+        if N % 4:                                             # e.g. the 7-label linear probe: pad the weight rows, slice the result
+            Np = (N + 3) // 4 * 4
+            wpad = _cached(weight, "bf16_rowpad", lambda t: Fn.to_bf16(torch.cat([t, t.new_zeros(Np - N, t.shape[1])]).contiguous()))
+            bpad = torch.cat([bias.detach(), bias.new_zeros(Np - N)]) if bias is not None else None
+            y = Fn.gemm(x2, wpad, bias=bpad, out_dtype=F32, k=weight.shape[1])[:, :N].contiguous()
+            if residual is not None:
+                raise ValueError("LinearFn: residual with N % 4 != 0 is not supported")
+            ctx.save_for_backward(x2, weight)
+            ctx.x_shape, ctx.has_bias, ctx.has_res = x.shape, bias is not None, False
+            return y.view(*x.shape[:-1], N)
         wb = weight_bf16(weight)
         res2 = residual.reshape(-1, weight.shape[0]).contiguous() if residual is not None else None
         y = Fn.gemm(x2, wb, bias=bias, residual=res2, out_dtype=F32, k=weight.shape[1])
@@ -69,6 +80,18 @@ class LinearFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, N).contiguous()
         dx = dw = db = None
         dyb = None
+        if N % 4:                                             # rare small-N path: pad dY's columns with zeros (layout plumbing)
+            Np = (N + 7) // 8 * 8
+            dyp = torch.zeros((dy2.shape[0], Np), dtype=F32, device=dy2.device)
+            dyp[:, :N] = dy2
+            if ctx.needs_input_grad[0]:
+                wt = _cached(weight, "t_bf16_colpad", lambda t: Fn.transpose_to_bf16(torch.cat([t, t.new_zeros(Np - N, K)]).contiguous()))
+                dx = Fn.gemm(Fn.to_bf16(dyp), wt, out_dtype=F32, k=Np).view(ctx.x_shape)
+            if ctx.needs_input_grad[1]:
+                dw = Fn.gemm(Fn.transpose_to_bf16(dyp), Fn.transpose_to_bf16(x2), out_dtype=F32)[:N].contiguous()
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = Fn.colsum(dy2)
+            return dx, dw, db, None
         if ctx.needs_input_grad[0]:
             dyb = Fn.to_bf16(dy2) if N % 4 == 0 else dy2.to(BF16)
             wt = weight_t_bf16(weight)                           # [K, Npad]
@@ -316,3 +339,79 @@ class StudentKDLossFn(torch.autograd.Function):
     def backward(ctx, dout):
         (g,) = ctx.saved_tensors
         return g * dout[0], None, None, None, None, None
+
+
+class _ScalarLossFn(torch.autograd.Function):
+    """Shared shape of the scalar extras: forward launches one kernel that writes value + gradient; backward scales it."""
+
+    @staticmethod
+    def forward(ctx, x, launch):
+        xc = x.contiguous().to(F32)
+        out = torch.empty(1, dtype=F32, device=x.device)
+        g = torch.empty_like(xc)
+        launch(xc, out, g)
+        ctx.save_for_backward(g)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, dout):
+        (g,) = ctx.saved_tensors
+        return g * dout, None
+
+
+def aux_residual_kl(img_logits, scaled_correction, y_multi, mask, smoothing=0.05):
+    """engine.py:149-165 — gradient flows through `scaled_correction` only (img_logits is detached)."""
+    img, y, m = (t.detach().contiguous().to(F32) for t in (img_logits, y_multi, mask))
+    return _ScalarLossFn.apply(scaled_correction, lambda x, out, g: check(
+        lib().medp_aux_residual_kl(ptr(img), ptr(x), ptr(y), ptr(m), smoothing, ptr(out), ptr(g), x.numel(), stream()), "aux_residual_kl"))
+
+
+def sq_mean(x, coef):
+    """coef * mean(x**2)   (engine.py:221,223)"""
+    return _ScalarLossFn.apply(x, lambda xc, out, g: check(lib().medp_sq_mean(ptr(xc), float(coef), ptr(out), ptr(g), xc.numel(), stream()), "sq_mean"))
+
+
+def masked_bce_global(logits, y, mask):
+    """cxr_linear_training.ipynb:426-437"""
+    yc, mc = (t.detach().contiguous().to(F32) for t in (y, mask))
+    return _ScalarLossFn.apply(logits, lambda x, out, g: check(
+        lib().medp_masked_bce_global(ptr(x), ptr(yc), ptr(mc), ptr(out), ptr(g), x.numel(), stream()), "masked_bce_global"))
+
+
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed, sid):
+        xc = x.contiguous()
+        out = torch.empty_like(xc)
+        check(lib().medp_dropout_add(ptr(xc), None, ptr(out), xc.numel(), p, seed, sid, stream()), "dropout")
+        ctx.cfg = (p, seed, sid)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        p, seed, sid = ctx.cfg
+        dc = dout.contiguous()
+        dx = torch.empty_like(dc)
+        check(lib().medp_dropout_add(ptr(dc), None, ptr(dx), dc.numel(), p, seed, sid, stream()), "dropout(bwd)")
+        return dx, None, None, None
+
+
+class _AddScaledFn(torch.autograd.Function):
+    """total = a + alpha * b for two scalar losses (host-free: stays on the device, no ATen arithmetic in the step)."""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        out = torch.empty(1, dtype=F32, device=a.device)
+        pair = torch.stack((a.reshape(()), b.reshape(())))             # layout plumbing: two scalars side by side
+        w = torch.tensor([1.0, alpha], dtype=F32).to(a.device, non_blocking=True)
+        check(lib().medp_rowdot_fwd(ptr(pair), 2, ptr(w), None, ptr(out), 1, 2, stream()), "add_scaled")
+        ctx.alpha = alpha
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, d * ctx.alpha, None
+
+
+def add_scaled(a, b, alpha):
+    return _AddScaledFn.apply(a, b, float(alpha))

@@ -242,6 +242,68 @@ __global__ __launch_bounds__(256) void meanpool_bwd_kernel(const float* __restri
     }
 }
 
+// ---- engine extras (training_duett/engine.py:149-165, 217-223) and the linear-probe loss (cxr_linear_training.ipynb:426-437) ----
+// aux residual KL: KL(Bern(y_smooth) || Bern(sigmoid(img.detach() + scaled))) masked mean; grad wrt `scaled` only.
+__global__ __launch_bounds__(256) void aux_kl_kernel(const float* __restrict__ img, const float* __restrict__ scaled, const float* __restrict__ y,
+                                                     const float* __restrict__ mask, float smooth, float* __restrict__ out,
+                                                     float* __restrict__ g, int n) {
+    __shared__ float red[2][4];
+    float num = 0.f, den = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float ys = y[i] * (1.f - smooth) + (1.f - y[i]) * smooth;
+        const float pr = 1.f / (1.f + __expf(-(img[i] + scaled[i])));
+        const float p = fminf(fmaxf(pr, 1e-6f), 1.f - 1e-6f);
+        num += (ys * (logf(ys) - logf(p)) + (1.f - ys) * (logf(1.f - ys) - logf(1.f - p))) * mask[i];
+        den += mask[i];
+    }
+    num = wave_sum(num);
+    den = wave_sum(den);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = num; red[1][threadIdx.x >> 6] = den; }
+    __syncthreads();
+    const float D = fmaxf((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]), 1.f);
+    if (threadIdx.x == 0) out[0] = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / D;
+    if (g) {
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const float ys = y[i] * (1.f - smooth) + (1.f - y[i]) * smooth;
+            const float pr = 1.f / (1.f + __expf(-(img[i] + scaled[i])));
+            const float inside = (pr > 1e-6f && pr < 1.f - 1e-6f) ? 1.f : 0.f;
+            const float p = fminf(fmaxf(pr, 1e-6f), 1.f - 1e-6f);
+            g[i] = inside * (-ys / p + (1.f - ys) / (1.f - p)) * pr * (1.f - pr) * mask[i] / D;
+        }
+    }
+}
+// out = coef * mean(x^2), g = 2*coef*x/n        (LP regularisers beta_l2*mean(beta^2), corr_l2*mean(scaled^2))
+__global__ __launch_bounds__(256) void sq_mean_kernel(const float* __restrict__ x, float coef, float* __restrict__ out, float* __restrict__ g, int n) {
+    __shared__ float red[4];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        a += x[i] * x[i];
+        if (g) g[i] = 2.f * coef * x[i] / (float)n;
+    }
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = coef * ((red[0] + red[1]) + (red[2] + red[3])) / (float)n;
+}
+// one global masked mean: sum(bce*m)/max(sum(m),1)   (config 2 linear probe)
+__global__ __launch_bounds__(256) void masked_bce_kernel(const float* __restrict__ l, const float* __restrict__ y, const float* __restrict__ mask,
+                                                         float* __restrict__ out, float* __restrict__ g, int n) {
+    __shared__ float red[2][4];
+    float num = 0.f, den = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        num += ((1.f - y[i]) * l[i] + softplus_neg(l[i])) * mask[i];
+        den += mask[i];
+    }
+    num = wave_sum(num);
+    den = wave_sum(den);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = num; red[1][threadIdx.x >> 6] = den; }
+    __syncthreads();
+    const float D = fmaxf((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]), 1.f);
+    if (threadIdx.x == 0) out[0] = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / D;
+    if (g)
+        for (int i = threadIdx.x; i < n; i += 256) g[i] = (1.f / (1.f + __expf(-l[i])) - y[i]) * mask[i] / D;
+}
+
 }  // namespace
 
 extern "C" int medp_gelu_dropout_fwd(const float* x, float* y, long long n, float p, unsigned seed, unsigned stream_id, void* stream) {
@@ -320,5 +382,25 @@ extern "C" int medp_meanpool_bwd(const float* dy, float* dx, int B, int T, int T
     MEDP_CHECK_ARG(dy && dx && B > 0 && T > 0 && T1 >= T && D > 0, "meanpool_bwd: bad argument");
     meanpool_bwd_kernel<<<grid_for((size_t)B * T1 * D), 256, 0, (hipStream_t)stream>>>(dy, dx, B, T, T1, D);
     MEDP_LAUNCH_CHECK("medp_meanpool_bwd");
+    return 0;
+}
+
+extern "C" int medp_aux_residual_kl(const float* img_logits, const float* scaled_correction, const float* y, const float* mask,
+                                    float label_smoothing, float* out, float* g_scaled, int n, void* stream) {
+    MEDP_CHECK_ARG(img_logits && scaled_correction && y && mask && out && n > 0, "aux_residual_kl: bad argument");
+    aux_kl_kernel<<<1, 256, 0, (hipStream_t)stream>>>(img_logits, scaled_correction, y, mask, label_smoothing, out, g_scaled, n);
+    MEDP_LAUNCH_CHECK("medp_aux_residual_kl");
+    return 0;
+}
+extern "C" int medp_sq_mean(const float* x, float coef, float* out, float* g, int n, void* stream) {
+    MEDP_CHECK_ARG(x && out && n > 0, "sq_mean: bad argument");
+    sq_mean_kernel<<<1, 256, 0, (hipStream_t)stream>>>(x, coef, out, g, n);
+    MEDP_LAUNCH_CHECK("medp_sq_mean");
+    return 0;
+}
+extern "C" int medp_masked_bce_global(const float* logits, const float* y, const float* mask, float* out, float* g, int n, void* stream) {
+    MEDP_CHECK_ARG(logits && y && mask && out && n > 0, "masked_bce_global: bad argument");
+    masked_bce_kernel<<<1, 256, 0, (hipStream_t)stream>>>(logits, y, mask, out, g, n);
+    MEDP_LAUNCH_CHECK("medp_masked_bce_global");
     return 0;
 }

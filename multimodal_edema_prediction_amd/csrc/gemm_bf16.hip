@@ -17,6 +17,8 @@
 //   * Fused epilogue: + bias[n] -> GELU(erf) -> * scale[n] (LayerScale) -> + residual[m,n] -> fp32 or bf16.
 //   * blockIdx -> tile map is XCD-aware (bijective): the 8 XCDs each get a contiguous run of tiles that
 //     walks N fastest, so one XCD's L2 sees one A row-panel and the whole W.
+#include <stdlib.h>
+
 #include <vector>
 
 #include "common.h"
@@ -162,6 +164,297 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const GemmParams p
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// v2: 256 x 128 x 64 tiles, 8 waves (4 x 2, 64 x 64 per wave), THREE LDS slots filled by LDS-DMA two K-tiles ahead.
+// One raw s_barrier per K-tile and a COUNTED s_waitcnt vmcnt (never 0 in the loop), so the loads of tiles t+1 / t+2 stay
+// in flight across the barrier while tile t is multiplied (cdna guide §5 "Pipelining across barriers").
+//   iteration t:  vmcnt(6)  -> tile t landed (this wave's 6 younger loads = tile t+1 may still fly)
+//                 s_barrier -> every wave's tile-t loads landed AND every wave finished reading slot (t-1)%3
+//                 issue tile t+2 into slot (t+2)%3 == (t-1)%3
+//                 ds_read + 32 MFMA on slot t%3
+template <int TAG>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v2_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = 256, BN = 128;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;   // 48 KiB, x3 = 144 KiB
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, kq = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+    const int nkt = (p.K + 63) >> 6;
+    const bf16_t* zero = (const bf16_t*)g_zero16;
+
+    // per-thread source rows are loop-invariant: precompute row base pointers (nullptr -> zero chunk)
+    auto stage = [&](int slot, int kt) {
+        char* sa = smem + slot * STAGE;
+        char* sb = sa + A_BYTES;
+        const int k0 = kt << 6;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int qd = i * 512 + tid;
+            const int row = qd >> 3, c = (qd & 7) ^ (row & 7);
+            const int gr = m0 + row, gk = k0 + c * 8;
+            const bf16_t* src = (gr < p.M && gk < p.K) ? p.A + (size_t)gr * p.lda + gk : zero;
+            glds16(src, sa + (i * 512 + wave * 64) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int qd = i * 512 + tid;
+            const int row = qd >> 3, c = (qd & 7) ^ (row & 7);
+            const int gr = n0 + row, gk = k0 + c * 8;
+            const bf16_t* src = (gr < p.N && gk < p.K) ? p.W + (size_t)gr * p.ldw + gk : zero;
+            glds16(src, sb + (i * 512 + wave * 64) * 16);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    stage(0, 0);
+    if (nkt > 1) stage(1, 1);
+
+    const int a_row0 = wr * 64 + fr, b_row0 = wc * 64 + fr;
+    const int sw = fr & 7;
+    int slot = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nkt) stage(slot == 0 ? 2 : slot - 1, kt + 2);      // (kt+2)%3 == (slot+2)%3
+        const char* sa = smem + slot * STAGE;
+        const char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int coff = ((s * 4 + kq) ^ sw) << 4;
+            bf16x8 xa[4], wb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xa[i] = *(const bf16x8*)(sa + (a_row0 + i * 16) * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wb[j] = *(const bf16x8*)(sb + (b_row0 + j * 16) * 128 + coff);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wr * 64 + i * 16 + fr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wc * 64 + j * 16 + kq * 4;
+            if (n >= p.N) continue;
+            f32x4 v = acc[i][j];
+            if (p.bias) v += *(const f32x4*)(p.bias + n);
+            if (p.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            }
+            if (p.scale) v *= *(const f32x4*)(p.scale + n);
+            if (p.residual) v += *(const f32x4*)(p.residual + (size_t)m * p.ldr + n);
+            if (p.out_bf16) {
+                uint2 o;
+                o.x = pack_bf2(v[0], v[1]);
+                o.y = pack_bf2(v[2], v[3]);
+                *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+            } else {
+                *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
+            }
+        }
+    }
+}
+
+template <int TAG>
+int launch_v2(const GemmParams& p, hipStream_t stream) {
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 127) / 128);
+    constexpr int LDS = 3 * (256 + 128) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm_bf16_nt_v2_kernel<TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    gemm_bf16_nt_v2_kernel<TAG><<<tiles, 512, LDS, stream>>>(p);
+    MEDP_LAUNCH_CHECK("medp_gemm_bf16_nt(v2)");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// v3: the LDS-traffic fix.  v1/v2 give each wave a 64x64 output tile: 32 flop per LDS byte read, and the LDS (fragment
+// reads + LDS-DMA fills) is as busy as the matrix pipe.  v3 gives each wave 128 x 64 (8 x 4 MFMA tiles, 128 accumulator
+// VGPRs): 43 flop per LDS byte, 12 ds_read_b128 per 32 MFMAs.
+//   block 256 x 128, 4 waves (2 x 2), BK = 32 (64-B LDS rows), THREE 24-KiB slots (72 KiB -> 2 blocks per CU),
+//   LDS-DMA two K-tiles ahead, counted vmcnt + one raw s_barrier per K-tile (same protocol as v2).
+//   64-B rows: chunk' = chunk ^ (((row >> 2) & 1) << 1) makes every ds_read_b128 lane group hit 16 distinct 16-B slots.
+template <int TAG>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_v3_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = 256, BN = 128;
+    constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;   // 24 KiB
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, kq = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+    const int nkt = (p.K + 31) >> 5;
+    const bf16_t* zero = (const bf16_t*)g_zero16;
+
+    // one 1-KiB LDS-DMA piece per call: pieces 0..3 = A rows, 4..5 = W rows of K-tile kt
+    auto stage_piece = [&](int slot, int kt, int piece) {
+        char* sa = smem + slot * STAGE;
+        const int k0 = kt << 5;
+        if (piece < 4) {
+            const int qd = piece * 256 + tid;
+            const int row = qd >> 2, c = (qd & 3) ^ (((row >> 2) & 1) << 1);
+            const int gr = m0 + row, gk = k0 + c * 8;
+            const bf16_t* src = (gr < p.M && gk < p.K) ? p.A + (size_t)gr * p.lda + gk : zero;
+            glds16(src, sa + (piece * 256 + wave * 64) * 16);
+        } else {
+            const int qd = (piece - 4) * 256 + tid;
+            const int row = qd >> 2, c = (qd & 3) ^ (((row >> 2) & 1) << 1);
+            const int gr = n0 + row, gk = k0 + c * 8;
+            const bf16_t* src = (gr < p.N && gk < p.K) ? p.W + (size_t)gr * p.ldw + gk : zero;
+            glds16(src, sa + A_BYTES + ((piece - 4) * 256 + wave * 64) * 16);
+        }
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int pc = 0; pc < 6; ++pc) stage_piece(0, 0, pc);
+    // tiles past the end of K are sourced from the zero chunk (bounds check in stage_piece), so the prefetch is issued
+    // unconditionally: no branch in the loop body, one basic block, and the wait is always vmcnt(6)
+#pragma unroll
+    for (int pc = 0; pc < 6; ++pc) stage_piece(1, 1, pc);
+
+    const int coff = (kq ^ (((fr >> 2) & 1) << 1)) << 4;
+    const int a_off = (wm * 128 + fr) * 64 + coff, b_off = (wn * 64 + fr) * 64 + coff;
+    int slot = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const char* sa = smem + slot * STAGE + a_off;
+        const char* sb = smem + slot * STAGE + A_BYTES + b_off;
+        const int nslot = slot == 0 ? 2 : slot - 1;
+        bf16x8 xa[8], wb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wb[j] = *(const bf16x8*)(sb + j * 16 * 64);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xa[i] = *(const bf16x8*)(sa + i * 16 * 64);
+        // MFMA rows in fragment-arrival order; the next-next tile's six LDS-DMA pieces are issued between the MFMA groups
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+            if (i < 6) stage_piece(nslot, kt + 2, i);
+        }
+        // shape the schedule: 6 fragment reads up front, then one more read behind every group of 4 MFMAs, so each MFMA group
+        // waits (counted lgkmcnt) only for the fragments it consumes instead of for all 12 reads
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+
+    // ---- epilogue through LDS: every global access is a whole 256-B (fp32) / 128-B (bf16) row segment ----------------
+    // Each wave owns a private [64][68] fp32 patch (17 KiB); two passes cover its 128 rows.  Accumulator layout (lane =
+    // output row, 4 consecutive columns) would store 32-B pieces of 16 different rows per instruction; after the LDS
+    // transpose a wave instruction covers 4 full rows, and bias / LayerScale / residual loads are coalesced too.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (zero-sourced) prefetches must land before LDS is reused
+    __syncthreads();                                   // last slot fully consumed by every wave, no LDS-DMA in flight
+    float* wl = (float*)(smem + wave * (64 * 68 * 4));
+    const int er = lane >> 4, ec = (lane & 15) * 4;
+    const int n = n0 + wn * 64 + ec;
+    f32x4 bias4 = (f32x4){0.f, 0.f, 0.f, 0.f}, scale4 = (f32x4){1.f, 1.f, 1.f, 1.f};
+    if (n < p.N) {
+        if (p.bias) bias4 = *(const f32x4*)(p.bias + n);
+        if (p.scale) scale4 = *(const f32x4*)(p.scale + n);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(f32x4*)(wl + (i4 * 16 + fr) * 68 + j * 16 + kq * 4) = acc[half * 4 + i4][j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int rr = it * 4 + er;
+            const int m = m0 + wm * 128 + half * 64 + rr;
+            f32x4 v = *(const f32x4*)(wl + rr * 68 + ec);
+            if (m < p.M && n < p.N) {
+                v += bias4;
+                if (p.act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                }
+                v *= scale4;
+                if (p.residual) v += *(const f32x4*)(p.residual + (size_t)m * p.ldr + n);
+                if (p.out_bf16) {
+                    uint2 o;
+                    o.x = pack_bf2(v[0], v[1]);
+                    o.y = pack_bf2(v[2], v[3]);
+                    *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+                } else {
+                    *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
+template <int TAG>
+int launch_v3(const GemmParams& p, hipStream_t stream) {
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 127) / 128);
+    constexpr int LDS = 3 * (256 + 128) * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm_bf16_nt_v3_kernel<TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    gemm_bf16_nt_v3_kernel<TAG><<<tiles, 256, LDS, stream>>>(p);
+    MEDP_LAUNCH_CHECK("medp_gemm_bf16_nt(v3)");
+    return 0;
+}
+
 template <int BM, int BN, int TAG>
 int launch(const GemmParams& p, hipStream_t stream) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
@@ -230,7 +523,12 @@ int medp_gemm_bf16_nt_tagged(int tag, const void* A, const void* W, void* C, int
     MEDP_CHECK_ARG(act == 0 || act == 1, "gemm: act must be 0 (none) or 1 (gelu)");
     GemmParams p{(const bf16_t*)A, (const bf16_t*)W, C, M, N, K, lda, ldw, ldc, bias, scale, residual, ldr, act, out_bf16};
     hipStream_t s = (hipStream_t)stream;
+    static const int force = [] { const char* e = getenv("MEDP_GEMM_VARIANT"); return e ? atoi(e) : 0; }();   // 1 = v1, 2 = v2 (A/B tests)
+    const bool use_v2 = force == 2;
+    const bool use_v3 = force == 3 || (force == 0 && M >= 2048 && N >= 256);
     if (N <= 64) return launch<128, 64, 0>(p, s);
+    if (use_v3 && tag != 1) return launch_v3<0>(p, s);
+    if (use_v2 && tag != 1) return launch_v2<0>(p, s);
     if (tag == 1) {
         const bool prof = g_prof.on;
         if (prof) {
@@ -243,7 +541,7 @@ int medp_gemm_bf16_nt_tagged(int tag, const void* A, const void* W, void* C, int
             }
             hipEventRecord(g_prof.ev[g_prof.used], s);
         }
-        const int rc = launch<128, 128, 1>(p, s);
+        const int rc = use_v3 ? launch_v3<1>(p, s) : (use_v2 ? launch_v2<1>(p, s) : launch<128, 128, 1>(p, s));
         if (prof) {
             hipEventRecord(g_prof.ev[g_prof.used + 1], s);
             g_prof.used += 2;

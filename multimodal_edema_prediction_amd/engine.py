@@ -53,7 +53,8 @@ def train_teacher_dual_pathology_batch(batch, teacher, path_loss_fn, optimizer, 
     total = losses["total"]
     aux_residual_loss = torch.zeros((), device=device)
     if aux_residual_alpha > 0.0 and "scaled_correction" in out:
-        raise NotImplementedError("aux residual KL (engine.py:149-165) is off by default (run.py:146) and not built yet")
+        aux_residual_loss = A.aux_residual_kl(out["img_logits"], out["scaled_correction"], b["y_multi"], b["y_multi_mask"], 0.05)
+        total = A.add_scaled(total, aux_residual_loss, aux_residual_alpha)
     optimizer.zero_grad()
     _backward(total, accelerator)
     optimizer.step()
@@ -100,3 +101,40 @@ def eval_student_batch(batch, student, device):
     b = _move_lists(batch, device)
     z = student(b["x_ts"], b["x_static"], b["bin_ends"])
     return {"logits": z, "y": b["y"]}
+
+
+def train_teacher_dual_pathology_lp_batch(batch, teacher, path_loss_fn, optimizer, device, accelerator=None, beta_l2: float = 0.0,
+                                          corr_l2: float = 0.0, aux_residual_alpha: float = 0.0):
+    """engine.py:196-264: everything in eval() except perceiver.correction_head; total = fusion losses + beta_l2*mean(beta^2)
+    + corr_l2*mean(scaled_correction^2) (+ aux KL)."""
+    teacher.eval()
+    unwrapped = accelerator.unwrap_model(teacher) if accelerator is not None else getattr(teacher, "module", teacher)
+    unwrapped.perceiver.correction_head.train()
+    b = _move_lists(batch, device)
+    out = teacher(b["x_ts"], b["x_static"], b["bin_ends"], b["pixel_values"])
+    if not isinstance(out, dict):
+        raise RuntimeError("dual_pathology LP mode but TeacherModel did not return a dict")
+    losses = path_loss_fn(out["img_logits"], out["ts_logits"], out["fusion_logits"], b["y_multi"], b["y_multi_mask"])
+    total = losses["total"]
+    reg_beta = torch.zeros((), device=device)
+    reg_corr = torch.zeros((), device=device)
+    aux_residual_loss = torch.zeros((), device=device)
+    if beta_l2 > 0.0:
+        reg_beta = A.sq_mean(unwrapped.perceiver.beta, beta_l2)
+        total = A.add_scaled(total, reg_beta, 1.0)
+    if corr_l2 > 0.0:
+        reg_corr = A.sq_mean(out["scaled_correction"], corr_l2)
+        total = A.add_scaled(total, reg_corr, 1.0)
+    if aux_residual_alpha > 0.0 and "scaled_correction" in out:
+        aux_residual_loss = A.aux_residual_kl(out["img_logits"], out["scaled_correction"], b["y_multi"], b["y_multi_mask"], 0.05)
+        total = A.add_scaled(total, aux_residual_loss, aux_residual_alpha)
+    optimizer.zero_grad()
+    _backward(total, accelerator)
+    optimizer.step()
+    return {"loss": total.detach().item(), "img_total": losses["img_total"].item(), "ts_total": losses["ts_total"].item(),
+            "fus_total": losses["fus_total"].item(), "img_per": losses["img_per"].cpu(), "ts_per": losses["ts_per"].cpu(),
+            "fus_per": losses["fus_per"].cpu(), "reg_beta_l2": float(reg_beta.detach().item()),
+            "reg_corr_l2": float(reg_corr.detach().item()), "aux_residual": float(aux_residual_loss.detach().item()),
+            "main_logit": out["main_logit"].detach(), "img_logits": out["img_logits"].detach(), "ts_logits": out["ts_logits"].detach(),
+            "fusion_logits": out["fusion_logits"].detach(), "y": b["y"].detach(), "y_multi": b["y_multi"].detach(),
+            "y_multi_mask": b["y_multi_mask"].detach()}

@@ -179,3 +179,75 @@ def test_fused_adamw_matches_torch_adamw():
         oa.step(); ob.step()
     for x, y in zip(a, b):
         assert float((x - y).abs().max()) < 2e-6
+
+
+def test_engine_extras_aux_kl_and_lp_regularisers(teacher, tbatch):
+    """engine.py:149-165, 217-223 against the reference values (golden) and their analytic gradients (torch on CPU)."""
+    from multimodal_edema_prediction_amd import autograd_ops as A
+    gold = load_npz("teacher_loss_cfg1.npz")
+    teacher.eval()
+    out, b = fwd(teacher, tbatch)
+    aux = A.aux_residual_kl(out["img_logits"], out["scaled_correction"], b["y_multi"], b["y_multi_mask"])
+    assert abs(float(aux) - float(gold["aux_kl"])) <= 1e-2 * abs(float(gold["aux_kl"]))
+    rb = A.sq_mean(teacher.perceiver.beta, 1e-3)
+    rc = A.sq_mean(out["scaled_correction"], 1e-2)
+    assert abs(float(rb) - float(gold["reg_beta"])) <= 1e-5 * abs(float(gold["reg_beta"])) + 1e-9
+    assert abs(float(rc) - float(gold["reg_corr"])) <= 5e-2 * abs(float(gold["reg_corr"])) + 1e-9
+    # gradient of the aux KL w.r.t. scaled_correction vs torch autograd on the same (GPU-produced) inputs
+    sc = out["scaled_correction"].detach().cpu().double().requires_grad_(True)
+    img = out["img_logits"].detach().cpu().double()
+    y, m = tbatch["y_multi"].double(), tbatch["y_multi_mask"].double()
+    ys = y * 0.95 + (1 - y) * 0.05
+    p = torch.sigmoid(img + sc).clamp(1e-6, 1 - 1e-6)
+    ref = ((ys * (ys.log() - p.log()) + (1 - ys) * ((1 - ys).log() - (1 - p).log())) * m).sum() / m.sum().clamp(min=1.0)
+    ref.backward()
+    x = out["scaled_correction"].detach().clone().requires_grad_(True)
+    A.aux_residual_kl(out["img_logits"], x, b["y_multi"], b["y_multi_mask"]).backward()
+    assert maxerr(x.grad, sc.grad.float()) < 1e-6
+    tot = A.add_scaled(aux, rb, 0.5)
+    assert abs(float(tot) - (float(aux) + 0.5 * float(rb))) < 1e-6
+
+
+def test_lp_step_only_moves_correction_head_and_beta(tbatch):
+    teacher = build_teacher()
+    for p in teacher.parameters():
+        p.requires_grad = False
+    for p in teacher.perceiver.correction_head.parameters():
+        p.requires_grad = True
+    teacher.perceiver.beta.requires_grad = True
+    before = {k: v.detach().clone() for k, v in teacher.named_parameters()}
+    loss_fn = DualPathologyLoss(torch.ones(K), None, 0.5, 0.5, 1.0).to(DEV)
+    opt = FusedAdamW([p for p in teacher.parameters() if p.requires_grad], lr=8e-5, weight_decay=5e-2)
+    out = engine.train_teacher_dual_pathology_lp_batch(tbatch, teacher, loss_fn, opt, torch.device(DEV), beta_l2=1e-3, corr_l2=1e-2,
+                                                        aux_residual_alpha=0.1)
+    assert out["reg_beta_l2"] > 0 and out["reg_corr_l2"] > 0 and out["aux_residual"] > 0
+    moved = {k for k, v in teacher.named_parameters() if not torch.equal(v.detach(), before[k])}
+    assert moved and all(("correction_head" in k or k.endswith(".beta")) for k in moved), moved
+
+
+def test_linear_probe_cfg2():
+    """RadDinoClassifier mirror: logits = Linear(768,7)(CLS) and the global masked BCE, vs the CPU oracle."""
+    from multimodal_edema_prediction_amd.linear_probe import RadDinoClassifier, masked_bce_with_logits_loss
+    from oracle import losses_ref, vit_ref
+    torch.manual_seed(0)
+    m = RadDinoClassifier("synthetic", num_classes=7, dropout=0.0)
+    m.encoder.backbone.load_state_dict(synth_state_dict(SHAPES["vit"], seed=3), strict=True)
+    m = m.to(DEV).train()
+    g = torch.Generator().manual_seed(5)
+    px = torch.randn(2, 3, 224, 224, generator=g)
+    y, mk = (torch.rand(2, 7, generator=g) < 0.3).float(), (torch.rand(2, 7, generator=g) < 0.8).float()
+    logits = m(px.to(DEV))
+    loss = masked_bce_with_logits_loss(logits, y.to(DEV), mk.to(DEV))
+    loss.backward()
+    with torch.no_grad():
+        cls, _ = vit_ref.vit_forward(synth_state_dict(SHAPES["vit"], seed=3), vit_ref.VitCfg(), px)
+    W = m.classifier[1].weight.detach().cpu().clone().requires_grad_(True)
+    bb = m.classifier[1].bias.detach().cpu().clone().requires_grad_(True)
+    ref_logits = torch.nn.functional.linear(cls, W, bb)
+    ref = losses_ref.masked_bce_global(ref_logits, y, mk)
+    ref.backward()
+    assert maxerr(logits, ref_logits.detach()) < 3e-2
+    assert abs(float(loss) - float(ref)) <= 1e-2 * abs(float(ref))
+    gw = m.classifier[1].weight.grad.cpu()
+    assert float((gw - W.grad).norm() / W.grad.norm()) < 0.05
+    assert maxerr(m.classifier[1].bias.grad, bb.grad) < 1e-3
