@@ -208,6 +208,34 @@ int medp_adamw_chunk_elems(void);   /* elements one workgroup updates; block b h
 int medp_adamw_multi(const MedpAdamTensor* dev_descs, const int* dev_block_tensor, const int* dev_block_chunk, int n_blocks,
                      float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
 
+/* ---- DuETT embedding stage in TRAINING form (student KD path; BatchNorm batch statistics, gradients everywhere) ------
+ * grouped tiny layers, group = variable: x [G,R,K], W [G,N,K], b [G,N]   (duett/duett.py:24-39,84-86,124-125,151-157) */
+int medp_glinear_fwd(const float* x, const float* W, const float* b, float* y, int G, int R, int K, int N, void* stream);
+size_t medp_glinear_bwd_workspace_bytes(int G, int R, int K, int N);
+int medp_glinear_bwd(const float* dy, const float* x, const float* W, float* dx, float* dW, float* db, float* workspace, int G, int R,
+                     int K, int N, void* stream);
+/* BatchNormLastDim over the R rows of every group (duett/duett.py:11-22): batch_stats=1 train (biased var normalises,
+ * unbiased updates running), 0 eval.  save_mean/save_var [G,C] feed the backward. */
+int medp_gbn_fwd(const float* x, const float* w, const float* b, float* running_mean, float* running_var, float* y, float* save_mean,
+                 float* save_var, int G, int R, int C, float eps, float momentum, int batch_stats, void* stream);
+int medp_gbn_bwd(const float* dy, const float* x, const float* w, const float* save_mean, const float* save_var, float* dx, float* dw,
+                 float* db, int G, int R, int C, float eps, int batch_stats, void* stream);
+int medp_act_fwd(const float* x, float* y, long long n, int mode /*0 relu, 1 tanh*/, void* stream);
+int medp_act_bwd(const float* dy, const float* y, float* dx, long long n, int mode, void* stream);
+/* (value, n_obs_embedding[clip(int(count),0,15)]) pairs per variable, zero-padded to KP columns (model :41-52) */
+int medp_embed_inputs_fwd(const float* xs_ts, const float* n_obs_table, int table_rows, float* xin, int B, int T, int V, int KP,
+                          void* stream);
+int medp_embed_inputs_bwd_blocks(int B, int T, int V);
+int medp_embed_inputs_bwd(const float* xs_ts, const float* d_xin, float* partial, int table_rows, int B, int T, int V, int KP,
+                          void* stream);
+/* psi assembly with special-token overrides (model :53-66) and its backward */
+int medp_psi_assemble_fwd(const float* xs_ts, const float* var_out, const float* tab_out, const float* special, float* psi, int B, int T,
+                          int V, int E, void* stream);
+int medp_psi_assemble_bwd(const float* xs_ts, const float* dpsi, float* d_var_out, float* d_tab_out, float* d_special_partial, int B,
+                          int T, int V, int E, void* stream);
+int medp_axis_swap(const float* in, float* out, int B, int A1, int A2, int E, void* stream);
+int medp_add_bcast(const float* a, const float* b, float* out, long long per_batch, int B, int broadcast_b, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

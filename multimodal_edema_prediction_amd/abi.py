@@ -90,6 +90,20 @@ SIGNATURES = {
     "medp_aux_residual_kl": (I, [P, P, P, P, F, P, P, I, P]),
     "medp_sq_mean": (I, [P, F, P, P, I, P]),
     "medp_masked_bce_global": (I, [P, P, P, P, P, I, P]),
+    "medp_glinear_fwd": (I, [P, P, P, P, I, I, I, I, P]),
+    "medp_glinear_bwd_workspace_bytes": (SZ, [I, I, I, I]),
+    "medp_glinear_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, P]),
+    "medp_gbn_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, F, F, I, P]),
+    "medp_gbn_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, F, I, P]),
+    "medp_act_fwd": (I, [P, P, LL, I, P]),
+    "medp_act_bwd": (I, [P, P, P, LL, I, P]),
+    "medp_embed_inputs_fwd": (I, [P, P, I, P, I, I, I, I, P]),
+    "medp_embed_inputs_bwd_blocks": (I, [I, I, I]),
+    "medp_embed_inputs_bwd": (I, [P, P, P, I, I, I, I, I, P]),
+    "medp_psi_assemble_fwd": (I, [P, P, P, P, P, I, I, I, I, P]),
+    "medp_psi_assemble_bwd": (I, [P, P, P, P, P, I, I, I, I, P]),
+    "medp_axis_swap": (I, [P, P, I, I, I, I, P]),
+    "medp_add_bcast": (I, [P, P, P, LL, I, I, P]),
     "medp_adamw_chunk_elems": (I, []),
     "medp_adamw_multi": (I, [P, P, P, I, F, F, F, I, F, P]),
 }

@@ -1,0 +1,393 @@
+// Training-form kernels of the DuETT embedding stage (student KD path: BatchNorm in TRAIN mode, gradients to every
+// DuETT parameter; reference duett/duett.py:11-39,84-88,124-125,151-157 + model file :41-69).
+// The per-variable MLPs are run as GROUPED tiny layers (group = variable): hidden activations are materialised
+// [G, R, C] so BatchNorm batch statistics and every weight gradient are plain column reductions — deterministic
+// two-stage sums, no float atomics.  All fp32; FLOPs are negligible, the cost is HBM traffic and launch count.
+#include "common.h"
+#include "medp_hip.h"
+
+namespace {
+
+inline int grid_for(size_t work_items) { return (int)min((size_t)4096, max((size_t)1, (work_items + 255) / 256)); }
+
+// ---- grouped tiny linear: y[g][r][n] = b[g][n] + sum_k W[g][n][k] x[g][r][k]      (N*K <= 8192) ---------------------
+__global__ __launch_bounds__(256) void glinear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
+                                                          float* __restrict__ y, int R, int K, int N) {
+    extern __shared__ float sw[];            // N*K weights + N bias
+    const int g = blockIdx.y;
+    for (int i = threadIdx.x; i < N * K; i += 256) sw[i] = W[(size_t)g * N * K + i];
+    for (int i = threadIdx.x; i < N; i += 256) sw[N * K + i] = b ? b[(size_t)g * N + i] : 0.f;
+    __syncthreads();
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const float* xr = x + ((size_t)g * R + r) * K;
+    float* yr = y + ((size_t)g * R + r) * N;
+    for (int n = 0; n < N; ++n) {
+        float a = sw[N * K + n];
+        const float* wr = sw + n * K;
+        for (int k = 0; k < K; ++k) a += wr[k] * xr[k];
+        yr[n] = a;
+    }
+}
+// dx[g][r][k] = sum_n dy[g][r][n] W[g][n][k]
+__global__ __launch_bounds__(256) void glinear_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ W, float* __restrict__ dx,
+                                                             int R, int K, int N) {
+    extern __shared__ float sw[];
+    const int g = blockIdx.y;
+    for (int i = threadIdx.x; i < N * K; i += 256) sw[i] = W[(size_t)g * N * K + i];
+    __syncthreads();
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const float* dr = dy + ((size_t)g * R + r) * N;
+    float* xr = dx + ((size_t)g * R + r) * K;
+    for (int k = 0; k < K; ++k) {
+        float a = 0.f;
+        for (int n = 0; n < N; ++n) a += dr[n] * sw[n * K + k];
+        xr[k] = a;
+    }
+}
+// partial[g][chunk][n*K+k] = sum_{r in chunk} dy[r][n] x[r][k] ;  partial_b[g][chunk][n] = sum dy[r][n]
+__global__ __launch_bounds__(256) void glinear_bwd_dw_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                     float* __restrict__ pw, float* __restrict__ pb, int R, int K, int N,
+                                                                     int rows_per_chunk) {
+    const int g = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int r0 = chunk * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+    const float* dyg = dy + (size_t)g * R * N;
+    const float* xg = x + (size_t)g * R * K;
+    for (int i = threadIdx.x; i < N * K; i += 256) {
+        const int n = i / K, k = i % K;
+        float a = 0.f;
+        for (int r = r0; r < r1; ++r) a += dyg[(size_t)r * N + n] * xg[(size_t)r * K + k];
+        pw[((size_t)g * nchunk + chunk) * N * K + i] = a;
+    }
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float a = 0.f;
+        for (int r = r0; r < r1; ++r) a += dyg[(size_t)r * N + n];
+        pb[((size_t)g * nchunk + chunk) * N + n] = a;
+    }
+}
+// out[g][i] = sum_chunk partial[g][chunk][i]
+__global__ __launch_bounds__(256) void sum_chunks_kernel(const float* __restrict__ partial, float* __restrict__ out, int nchunk, int D) {
+    const int g = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= D) return;
+    float a = 0.f;
+    for (int c = 0; c < nchunk; ++c) a += partial[((size_t)g * nchunk + c) * D + i];
+    out[(size_t)g * D + i] = a;
+}
+
+// ---- grouped BatchNorm over rows: x [G][R][C], statistics per (g, c) ------------------------------------------------
+// stats kernel: block = 64 columns x 4 row-lanes, loops every row (two sweeps: mean, then centred second moment)
+__global__ __launch_bounds__(256) void gbn_stats_kernel(const float* __restrict__ x, float* __restrict__ mean, float* __restrict__ var, int R, int C) {
+    __shared__ float red[4][64];
+    const int g = blockIdx.y, cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    const float* xg = x + (size_t)g * R * C;
+    float s = 0.f;
+    if (c < C) for (int r = rl; r < R; r += 4) s += xg[(size_t)r * C + c];
+    red[rl][cl] = s;
+    __syncthreads();
+    const float mu = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) / (float)R;
+    __syncthreads();
+    float q = 0.f;
+    if (c < C) for (int r = rl; r < R; r += 4) { const float d = xg[(size_t)r * C + c] - mu; q += d * d; }
+    red[rl][cl] = q;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        mean[(size_t)g * C + c] = mu;
+        var[(size_t)g * C + c] = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) / (float)R;   // biased
+    }
+}
+// running = (1-m)*running + m*batch  (unbiased variance), num_batches_tracked handled by the caller
+__global__ __launch_bounds__(256) void gbn_running_kernel(const float* __restrict__ mean, const float* __restrict__ var, float* __restrict__ rmean,
+                                                          float* __restrict__ rvar, int n, int R, float momentum) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    rmean[i] = (1.f - momentum) * rmean[i] + momentum * mean[i];
+    rvar[i] = (1.f - momentum) * rvar[i] + momentum * var[i] * ((float)R / (float)max(R - 1, 1));
+}
+__global__ __launch_bounds__(256) void gbn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ var,
+                                                        const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ y,
+                                                        int G, int R, int C, float eps) {
+    const size_t n = (size_t)G * R * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C), g = (int)(i / ((size_t)R * C));
+        const int gc = g * C + c;
+        y[i] = (x[i] - mean[gc]) * rsqrtf(var[gc] + eps) * w[gc] + b[gc];
+    }
+}
+// sums for backward: s1[g][c] = sum_r dy ; s2[g][c] = sum_r dy * xhat
+__global__ __launch_bounds__(256) void gbn_bwd_sums_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ var, float* __restrict__ s1, float* __restrict__ s2, int R,
+                                                           int C, float eps) {
+    __shared__ float red[2][4][64];
+    const int g = blockIdx.y, cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    float a = 0.f, q = 0.f;
+    if (c < C) {
+        const float mu = mean[(size_t)g * C + c], rs = rsqrtf(var[(size_t)g * C + c] + eps);
+        for (int r = rl; r < R; r += 4) {
+            const size_t i = ((size_t)g * R + r) * C + c;
+            a += dy[i];
+            q += dy[i] * (x[i] - mu) * rs;
+        }
+    }
+    red[0][rl][cl] = a;
+    red[1][rl][cl] = q;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        s1[(size_t)g * C + c] = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+        s2[(size_t)g * C + c] = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    }
+}
+// train: dx = w*rstd*(dy - s1/R - xhat*s2/R) ; eval (batch_stats == 0): dx = w*rstd*dy
+__global__ __launch_bounds__(256) void gbn_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                                                         const float* __restrict__ var, const float* __restrict__ w, const float* __restrict__ s1,
+                                                         const float* __restrict__ s2, float* __restrict__ dx, int G, int R, int C, float eps,
+                                                         int batch_stats) {
+    const size_t n = (size_t)G * R * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C), g = (int)(i / ((size_t)R * C));
+        const int gc = g * C + c;
+        const float rs = rsqrtf(var[gc] + eps);
+        float v = dy[i];
+        if (batch_stats) v -= s1[gc] / (float)R + (x[i] - mean[gc]) * rs * s2[gc] / (float)R;
+        dx[i] = w[gc] * rs * v;
+    }
+}
+
+// ---- activations: mode 0 = ReLU, 1 = tanh --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, int mode) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        y[i] = mode == 0 ? fmaxf(x[i], 0.f) : tanhf(x[i]);
+}
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, size_t n, int mode) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        dx[i] = mode == 0 ? (y[i] > 0.f ? dy[i] : 0.f) : dy[i] * (1.f - y[i] * y[i]);
+}
+
+// ---- embedding inputs: xin[v][b*T+t][0] = value, [1] = n_obs_table[clip(int(count))], [2..KP) = 0   (model :41-52) -----
+__global__ __launch_bounds__(256) void embed_inputs_fwd_kernel(const float* __restrict__ xs, const float* __restrict__ table, int nrows_table,
+                                                               float* __restrict__ xin, int B, int T, int V, int KP) {
+    const size_t n = (size_t)V * B * T;
+    const int F = 2 * V + 1;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i % ((size_t)B * T)), v = (int)(i / ((size_t)B * T));
+        const float* row = xs + (size_t)r * F;
+        const int idx = min(max((int)row[V + v], 0), nrows_table - 1);
+        float* o = xin + i * KP;
+        o[0] = row[v];
+        o[1] = table[idx];
+        for (int k = 2; k < KP; ++k) o[k] = 0.f;
+    }
+}
+// d_table partials: each block accumulates its elements' d_xin[...,1] into 16 LDS bins (LDS atomics: exact order within a
+// block is irrelevant to the bins' values up to fp32 rounding; the cross-block sum is a deterministic column sum)
+__global__ __launch_bounds__(256) void embed_inputs_bwd_kernel(const float* __restrict__ xs, const float* __restrict__ dxin, float* __restrict__ partial,
+                                                               int nrows_table, int B, int T, int V, int KP) {
+    __shared__ float bins[64];
+    if (threadIdx.x < 64) bins[threadIdx.x] = 0.f;
+    __syncthreads();
+    const size_t n = (size_t)V * B * T;
+    const int F = 2 * V + 1;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i % ((size_t)B * T)), v = (int)(i / ((size_t)B * T));
+        const int idx = min(max((int)xs[(size_t)r * F + V + v], 0), nrows_table - 1);
+        atomicAdd(&bins[idx], dxin[i * KP + 1]);
+    }
+    __syncthreads();
+    if (threadIdx.x < nrows_table) partial[(size_t)blockIdx.x * nrows_table + threadIdx.x] = bins[threadIdx.x];
+}
+
+// ---- psi assembly (model :53-66) and its backward -------------------------------------------------------------------------
+// psi[b][t][v][:] = var_out[v][b*T+t][:] | tab_out[b][:] (v == V) | special[0] (masked timestep / masked event) | special[1] (t == T)
+__device__ __forceinline__ int psi_cell_kind(const float* __restrict__ xs, int b, int t, int v, int T, int V) {
+    if (t == T) return 3;                                   // REP row
+    const float* row = xs + ((size_t)b * T + t) * (2 * V + 1);
+    if (row[2 * V] == 1.0f) return 2;                       // masked timestep
+    if (v == V) return 1;                                   // static column
+    if (row[V + v] == -1.0f) return 2;                      // masked event
+    return 0;                                               // variable MLP output
+}
+__global__ __launch_bounds__(256) void psi_assemble_fwd_kernel(const float* __restrict__ xs, const float* __restrict__ var_out,
+                                                               const float* __restrict__ tab_out, const float* __restrict__ special,
+                                                               float* __restrict__ psi, int B, int T, int V, int E) {
+    const int E4 = E / 4;
+    const size_t n = (size_t)B * (T + 1) * (V + 1) * E4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int e4 = (int)(i % E4);
+        size_t c = i / E4;
+        const int v = (int)(c % (V + 1));
+        c /= (V + 1);
+        const int t = (int)(c % (T + 1)), b = (int)(c / (T + 1));
+        const int kind = psi_cell_kind(xs, b, t, v, T, V);
+        const float* src = kind == 0 ? var_out + (((size_t)v * B + b) * T + t) * E : kind == 1 ? tab_out + (size_t)b * E
+                         : kind == 2 ? special : special + E;
+        *(float4*)(psi + i * 4) = *(const float4*)(src + e4 * 4);
+    }
+}
+// d_var_out (zero where overridden); per-batch partials of d_tab [B][E] and d_special [B][2][E] (summed over B by colsum)
+__global__ __launch_bounds__(256) void psi_assemble_bwd_kernel(const float* __restrict__ xs, const float* __restrict__ dpsi, float* __restrict__ d_var,
+                                                               float* __restrict__ d_tab, float* __restrict__ d_special_part, int B, int T, int V,
+                                                               int E) {
+    extern __shared__ float acc[];          // [3][E]: tab, special0, special1
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < 3 * E; i += 256) acc[i] = 0.f;
+    __syncthreads();
+    const int cells = (T + 1) * (V + 1);
+    for (int cidx = threadIdx.x; cidx < cells; cidx += 256) {
+        const int t = cidx / (V + 1), v = cidx % (V + 1);
+        const int kind = psi_cell_kind(xs, b, t, v, T, V);
+        const float* g = dpsi + (((size_t)b * (T + 1) + t) * (V + 1) + v) * E;
+        if (v < V && t < T) {
+            float* o = d_var + (((size_t)v * B + b) * T + t) * E;
+            for (int e = 0; e < E; ++e) o[e] = kind == 0 ? g[e] : 0.f;
+        }
+        if (kind != 0) {
+            float* a = acc + (kind - 1) * E;
+            for (int e = 0; e < E; ++e) atomicAdd(&a[e], g[e]);
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < E; e += 256) {
+        d_tab[(size_t)b * E + e] = acc[e];
+        d_special_part[((size_t)b * 2 + 0) * E + e] = acc[E + e];
+        d_special_part[((size_t)b * 2 + 1) * E + e] = acc[2 * E + e];
+    }
+}
+
+// plain axis swap of E-float cells: out[b][a2][a1][:] = in[b][a1][a2][:]
+__global__ __launch_bounds__(256) void axis_swap_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int A1, int A2, int E4) {
+    const size_t total = (size_t)B * A1 * A2 * E4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int e4 = (int)(i % E4);
+        size_t r = i / E4;
+        const int a1 = (int)(r % A1);
+        r /= A1;
+        const int a2 = (int)(r % A2), b = (int)(r / A2);
+        *(float4*)(out + i * 4) = *(const float4*)(in + ((((size_t)b * A1 + a1) * A2 + a2) * E4 + e4) * 4);
+    }
+}
+// out = a + b  (b broadcast over the leading batch dim when b_bs == 0)
+__global__ __launch_bounds__(256) void add_bcast_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t per_batch,
+                                                        int B, int bcast) {
+    const size_t n = per_batch * B;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+        const float4 x = *(const float4*)(a + i);
+        const float4 y = *(const float4*)(b + (bcast ? i % per_batch : i));
+        *(float4*)(out + i) = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    }
+}
+
+int dw_chunks(int R) { return max(1, min(64, R / 96)); }
+
+}  // namespace
+
+extern "C" int medp_glinear_fwd(const float* x, const float* W, const float* b, float* y, int G, int R, int K, int N, void* stream) {
+    MEDP_CHECK_ARG(x && W && y && G > 0 && R > 0 && K > 0 && N > 0 && (size_t)N * K + N <= 16000, "glinear_fwd: bad argument");
+    glinear_fwd_kernel<<<dim3((R + 255) / 256, G), 256, ((size_t)N * K + N) * 4, (hipStream_t)stream>>>(x, W, b, y, R, K, N);
+    MEDP_LAUNCH_CHECK("medp_glinear_fwd");
+    return 0;
+}
+extern "C" size_t medp_glinear_bwd_workspace_bytes(int G, int R, int K, int N) { return (size_t)G * dw_chunks(R) * ((size_t)N * K + N) * 4; }
+extern "C" int medp_glinear_bwd(const float* dy, const float* x, const float* W, float* dx, float* dW, float* db, float* workspace, int G,
+                                int R, int K, int N, void* stream) {
+    MEDP_CHECK_ARG(dy && x && W && G > 0 && R > 0 && K > 0 && N > 0 && (size_t)N * K <= 16000, "glinear_bwd: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (dx) {
+        glinear_bwd_dx_kernel<<<dim3((R + 255) / 256, G), 256, (size_t)N * K * 4, s>>>(dy, W, dx, R, K, N);
+        MEDP_LAUNCH_CHECK("medp_glinear_bwd(dx)");
+    }
+    if (dW) {
+        MEDP_CHECK_ARG(workspace && db, "glinear_bwd: dW needs db and a workspace");
+        const int nc = dw_chunks(R), rpc = (R + nc - 1) / nc;
+        float* pw = workspace;
+        float* pb = workspace + (size_t)G * nc * N * K;
+        glinear_bwd_dw_partial_kernel<<<dim3(nc, G), 256, 0, s>>>(dy, x, pw, pb, R, K, N, rpc);
+        MEDP_LAUNCH_CHECK("medp_glinear_bwd(partial)");
+        sum_chunks_kernel<<<dim3((N * K + 255) / 256, G), 256, 0, s>>>(pw, dW, nc, N * K);
+        sum_chunks_kernel<<<dim3((N + 255) / 256, G), 256, 0, s>>>(pb, db, nc, N);
+        MEDP_LAUNCH_CHECK("medp_glinear_bwd(final)");
+    }
+    return 0;
+}
+extern "C" int medp_gbn_fwd(const float* x, const float* w, const float* b, float* running_mean, float* running_var, float* y,
+                            float* save_mean, float* save_var, int G, int R, int C, float eps, float momentum, int batch_stats, void* stream) {
+    MEDP_CHECK_ARG(x && w && b && y && save_mean && save_var && G > 0 && R > 0 && C > 0, "gbn_fwd: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (batch_stats) {
+        gbn_stats_kernel<<<dim3((C + 63) / 64, G), 256, 0, s>>>(x, save_mean, save_var, R, C);
+        MEDP_LAUNCH_CHECK("medp_gbn_fwd(stats)");
+        if (running_mean && running_var) {
+            gbn_running_kernel<<<(G * C + 255) / 256, 256, 0, s>>>(save_mean, save_var, running_mean, running_var, G * C, R, momentum);
+            MEDP_LAUNCH_CHECK("medp_gbn_fwd(running)");
+        }
+    } else {
+        MEDP_CHECK_ARG(running_mean && running_var, "gbn_fwd: eval mode needs running statistics");
+        hipMemcpyAsync(save_mean, running_mean, (size_t)G * C * 4, hipMemcpyDeviceToDevice, s);
+        hipMemcpyAsync(save_var, running_var, (size_t)G * C * 4, hipMemcpyDeviceToDevice, s);
+    }
+    gbn_apply_kernel<<<grid_for((size_t)G * R * C), 256, 0, s>>>(x, save_mean, save_var, w, b, y, G, R, C, eps);
+    MEDP_LAUNCH_CHECK("medp_gbn_fwd(apply)");
+    return 0;
+}
+extern "C" int medp_gbn_bwd(const float* dy, const float* x, const float* w, const float* save_mean, const float* save_var, float* dx,
+                            float* dw, float* db, int G, int R, int C, float eps, int batch_stats, void* stream) {
+    MEDP_CHECK_ARG(dy && x && w && save_mean && save_var && dx && dw && db && G > 0 && R > 0 && C > 0, "gbn_bwd: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    gbn_bwd_sums_kernel<<<dim3((C + 63) / 64, G), 256, 0, s>>>(dy, x, save_mean, save_var, db, dw, R, C, eps);
+    MEDP_LAUNCH_CHECK("medp_gbn_bwd(sums)");
+    gbn_bwd_dx_kernel<<<grid_for((size_t)G * R * C), 256, 0, s>>>(dy, x, save_mean, save_var, w, db, dw, dx, G, R, C, eps, batch_stats);
+    MEDP_LAUNCH_CHECK("medp_gbn_bwd(dx)");
+    return 0;
+}
+extern "C" int medp_act_fwd(const float* x, float* y, long long n, int mode, void* stream) {
+    MEDP_CHECK_ARG(x && y && n > 0 && (mode == 0 || mode == 1), "act_fwd: bad argument");
+    act_fwd_kernel<<<grid_for((size_t)n), 256, 0, (hipStream_t)stream>>>(x, y, (size_t)n, mode);
+    MEDP_LAUNCH_CHECK("medp_act_fwd");
+    return 0;
+}
+extern "C" int medp_act_bwd(const float* dy, const float* y, float* dx, long long n, int mode, void* stream) {
+    MEDP_CHECK_ARG(dy && y && dx && n > 0 && (mode == 0 || mode == 1), "act_bwd: bad argument");
+    act_bwd_kernel<<<grid_for((size_t)n), 256, 0, (hipStream_t)stream>>>(dy, y, dx, (size_t)n, mode);
+    MEDP_LAUNCH_CHECK("medp_act_bwd");
+    return 0;
+}
+extern "C" int medp_embed_inputs_fwd(const float* xs_ts, const float* n_obs_table, int table_rows, float* xin, int B, int T, int V, int KP, void* stream) {
+    MEDP_CHECK_ARG(xs_ts && n_obs_table && xin && B > 0 && T > 0 && V > 0 && KP >= 2 && table_rows > 0 && table_rows <= 64, "embed_inputs_fwd: bad argument");
+    embed_inputs_fwd_kernel<<<grid_for((size_t)V * B * T), 256, 0, (hipStream_t)stream>>>(xs_ts, n_obs_table, table_rows, xin, B, T, V, KP);
+    MEDP_LAUNCH_CHECK("medp_embed_inputs_fwd");
+    return 0;
+}
+extern "C" int medp_embed_inputs_bwd_blocks(int B, int T, int V) { return min(256, grid_for((size_t)V * B * T)); }
+extern "C" int medp_embed_inputs_bwd(const float* xs_ts, const float* d_xin, float* partial /*[blocks][table_rows]*/, int table_rows, int B, int T,
+                                     int V, int KP, void* stream) {
+    MEDP_CHECK_ARG(xs_ts && d_xin && partial && table_rows > 0 && table_rows <= 64, "embed_inputs_bwd: bad argument");
+    embed_inputs_bwd_kernel<<<medp_embed_inputs_bwd_blocks(B, T, V), 256, 0, (hipStream_t)stream>>>(xs_ts, d_xin, partial, table_rows, B, T, V, KP);
+    MEDP_LAUNCH_CHECK("medp_embed_inputs_bwd");
+    return 0;
+}
+extern "C" int medp_psi_assemble_fwd(const float* xs_ts, const float* var_out, const float* tab_out, const float* special, float* psi, int B,
+                                     int T, int V, int E, void* stream) {
+    MEDP_CHECK_ARG(xs_ts && var_out && tab_out && special && psi && E % 4 == 0, "psi_assemble_fwd: bad argument");
+    psi_assemble_fwd_kernel<<<grid_for((size_t)B * (T + 1) * (V + 1) * E / 4), 256, 0, (hipStream_t)stream>>>(xs_ts, var_out, tab_out, special, psi, B, T, V, E);
+    MEDP_LAUNCH_CHECK("medp_psi_assemble_fwd");
+    return 0;
+}
+extern "C" int medp_psi_assemble_bwd(const float* xs_ts, const float* dpsi, float* d_var_out, float* d_tab_out, float* d_special_partial /*[B][2][E]*/,
+                                     int B, int T, int V, int E, void* stream) {
+    MEDP_CHECK_ARG(xs_ts && dpsi && d_var_out && d_tab_out && d_special_partial, "psi_assemble_bwd: bad argument");
+    psi_assemble_bwd_kernel<<<B, 256, 3 * E * sizeof(float), (hipStream_t)stream>>>(xs_ts, dpsi, d_var_out, d_tab_out, d_special_partial, B, T, V, E);
+    MEDP_LAUNCH_CHECK("medp_psi_assemble_bwd");
+    return 0;
+}
+extern "C" int medp_axis_swap(const float* in, float* out, int B, int A1, int A2, int E, void* stream) {
+    MEDP_CHECK_ARG(in && out && B > 0 && A1 > 0 && A2 > 0 && E % 4 == 0, "axis_swap: bad argument");
+    axis_swap_kernel<<<grid_for((size_t)B * A1 * A2 * E / 4), 256, 0, (hipStream_t)stream>>>(in, out, B, A1, A2, E / 4);
+    MEDP_LAUNCH_CHECK("medp_axis_swap");
+    return 0;
+}
+extern "C" int medp_add_bcast(const float* a, const float* b, float* out, long long per_batch, int B, int broadcast_b, void* stream) {
+    MEDP_CHECK_ARG(a && b && out && per_batch > 0 && per_batch % 4 == 0 && B > 0, "add_bcast: bad argument");
+    add_bcast_kernel<<<grid_for((size_t)per_batch * B / 4), 256, 0, (hipStream_t)stream>>>(a, b, out, (size_t)per_batch, B, broadcast_b);
+    MEDP_LAUNCH_CHECK("medp_add_bcast");
+    return 0;
+}

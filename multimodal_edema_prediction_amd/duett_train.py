@@ -1,0 +1,325 @@
+"""Training form of `DuettFeatureExtractor.encode` (model file :31-94): BatchNorm with batch statistics when the module is
+in train(), dropout inside the encoders, and gradients to every DuETT parameter — the student-KD path
+(`StudentModel`, engine.py:270-301) and a teacher with an unfrozen DuETT.  Composition of autograd Functions whose
+forward/backward are HIP kernels (C ABI); torch is used for stacking the V per-variable parameter sets into grouped
+operands and for autograd bookkeeping only.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import autograd_ops as A
+from . import functional as Fn
+from .abi import check, lib, ptr, stream
+
+F32 = torch.float32
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+# ------------------------------------------------------------------------------------------------ grouped tiny layers
+class GLinearFn(torch.autograd.Function):
+    """x [G,R,K], W [G,N,K], b [G,N] -> [G,R,N]"""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x, W, b = x.contiguous(), W.contiguous(), b.contiguous()
+        G, R, K = x.shape
+        N = W.shape[1]
+        y = torch.empty((G, R, N), dtype=F32, device=x.device)
+        check(lib().medp_glinear_fwd(ptr(x), ptr(W), ptr(b), ptr(y), G, R, K, N, stream()), "glinear_fwd")
+        ctx.save_for_backward(x, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        G, R, K = x.shape
+        N = W.shape[1]
+        dy = dy.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW, db = torch.empty_like(W), torch.empty((G, N), dtype=F32, device=x.device)
+        ws = torch.empty(lib().medp_glinear_bwd_workspace_bytes(G, R, K, N) // 4, dtype=F32, device=x.device)
+        check(lib().medp_glinear_bwd(ptr(dy), ptr(x), ptr(W), ptr(dx), ptr(dW), ptr(db), ptr(ws), G, R, K, N, stream()), "glinear_bwd")
+        return dx, dW, db
+
+
+class ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mode):
+        xc = x.contiguous()
+        y = torch.empty_like(xc)
+        check(lib().medp_act_fwd(ptr(xc), ptr(y), xc.numel(), mode, stream()), "act_fwd")
+        ctx.save_for_backward(y)
+        ctx.mode = mode
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dyc = dy.contiguous()
+        dx = torch.empty_like(y)
+        check(lib().medp_act_bwd(ptr(dyc), ptr(y), ptr(dx), y.numel(), ctx.mode, stream()), "act_bwd")
+        return dx, None
+
+
+class GBatchNormFn(torch.autograd.Function):
+    """BatchNorm over the R rows of each group.  x [G,R,C]; w, b, running_* [G,C] (running stats updated in place in train)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, rmean, rvar, batch_stats):
+        x, w, b = x.contiguous(), w.contiguous(), b.contiguous()
+        G, R, C = x.shape
+        y = torch.empty_like(x)
+        sm = torch.empty((G, C), dtype=F32, device=x.device)
+        sv = torch.empty((G, C), dtype=F32, device=x.device)
+        check(lib().medp_gbn_fwd(ptr(x), ptr(w), ptr(b), ptr(rmean), ptr(rvar), ptr(y), ptr(sm), ptr(sv), G, R, C, BN_EPS, BN_MOMENTUM,
+                                 int(batch_stats), stream()), "gbn_fwd")
+        ctx.save_for_backward(x, w, sm, sv)
+        ctx.batch_stats = batch_stats
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, sm, sv = ctx.saved_tensors
+        G, R, C = x.shape
+        dyc = dy.contiguous()
+        dx, dw, db = torch.empty_like(x), torch.empty_like(w), torch.empty_like(w)
+        check(lib().medp_gbn_bwd(ptr(dyc), ptr(x), ptr(w), ptr(sm), ptr(sv), ptr(dx), ptr(dw), ptr(db), G, R, C, BN_EPS,
+                                 int(ctx.batch_stats), stream()), "gbn_bwd")
+        return dx, dw, db, None, None, None
+
+
+class EmbedInputsFn(torch.autograd.Function):
+    """(value, n_obs_embedding[clip(int(count))]) per variable: xs_feats [B,T,2V+1], table [16,1] -> [V, B*T, 2]"""
+
+    @staticmethod
+    def forward(ctx, xs, table):
+        xs = xs.contiguous()
+        B, T, Fd = xs.shape
+        V = (Fd - 1) // 2
+        tab = table.reshape(-1).contiguous()
+        xin = torch.empty((V, B * T, 2), dtype=F32, device=xs.device)
+        check(lib().medp_embed_inputs_fwd(ptr(xs), ptr(tab), tab.numel(), ptr(xin), B, T, V, 2, stream()), "embed_inputs_fwd")
+        ctx.save_for_backward(xs)
+        ctx.cfg = (B, T, V, tab.numel(), tuple(table.shape))
+        return xin
+
+    @staticmethod
+    def backward(ctx, dxin):
+        (xs,) = ctx.saved_tensors
+        B, T, V, rows, tshape = ctx.cfg
+        nb = lib().medp_embed_inputs_bwd_blocks(B, T, V)
+        part = torch.empty((nb, rows), dtype=F32, device=xs.device)
+        d = dxin.contiguous()
+        check(lib().medp_embed_inputs_bwd(ptr(xs), ptr(d), ptr(part), rows, B, T, V, 2, stream()), "embed_inputs_bwd")
+        return None, Fn.colsum(part).view(tshape)
+
+
+class PsiAssembleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xs, var_out, tab_out, special):
+        xs, var_out, tab_out, special = xs.contiguous(), var_out.contiguous(), tab_out.contiguous(), special.contiguous()
+        B, T, Fd = xs.shape
+        V = (Fd - 1) // 2
+        E = special.shape[1]
+        psi = torch.empty((B, T + 1, V + 1, E), dtype=F32, device=xs.device)
+        check(lib().medp_psi_assemble_fwd(ptr(xs), ptr(var_out), ptr(tab_out), ptr(special), ptr(psi), B, T, V, E, stream()), "psi_assemble_fwd")
+        ctx.save_for_backward(xs)
+        ctx.cfg = (B, T, V, E, special.shape[0])
+        return psi
+
+    @staticmethod
+    def backward(ctx, dpsi):
+        (xs,) = ctx.saved_tensors
+        B, T, V, E, n_special = ctx.cfg
+        d = dpsi.contiguous()
+        d_var = torch.empty((V, B * T, E), dtype=F32, device=xs.device)
+        d_tab = torch.empty((B, E), dtype=F32, device=xs.device)
+        part = torch.empty((B, 2 * E), dtype=F32, device=xs.device)
+        check(lib().medp_psi_assemble_bwd(ptr(xs), ptr(d), ptr(d_var), ptr(d_tab), ptr(part), B, T, V, E, stream()), "psi_assemble_bwd")
+        d_special = torch.zeros((n_special, E), dtype=F32, device=xs.device)
+        d_special[:2] = Fn.colsum(part).view(2, E)
+        return None, d_var, d_tab, d_special
+
+
+class AxisSwapFn(torch.autograd.Function):
+    """[B, A1, A2, E] -> [B, A2, A1, E] (whole E-float cells)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, A1, A2, E = x.shape
+        y = torch.empty((B, A2, A1, E), dtype=F32, device=x.device)
+        check(lib().medp_axis_swap(ptr(x), ptr(y), B, A1, A2, E, stream()), "axis_swap")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        B, A2, A1, E = dy.shape
+        dx = torch.empty((B, A1, A2, E), dtype=F32, device=dy.device)
+        check(lib().medp_axis_swap(ptr(dy), ptr(dx), B, A2, A1, E, stream()), "axis_swap(bwd)")
+        return dx
+
+
+class AddBcastFn(torch.autograd.Function):
+    """a [B, ...] + b, where b is either [B, ...] or [...] broadcast over the batch."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        B = a.shape[0]
+        per = a.numel() // B
+        bcast = b.numel() == per
+        out = torch.empty_like(a)
+        check(lib().medp_add_bcast(ptr(a), ptr(b), ptr(out), per, B, int(bcast), stream()), "add_bcast")
+        ctx.cfg = (B, per, bcast, tuple(b.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        B, per, bcast, bshape = ctx.cfg
+        db = Fn.colsum(d.contiguous().view(B, per)).view(bshape) if bcast else d
+        return d, db
+
+
+class ScaleNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g, eps):
+        xc = x.contiguous()
+        y, rn = Fn.scalenorm(xc, g, eps, out_dtype=F32, save_rnorm=True)
+        ctx.save_for_backward(xc, g, rn)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, rn = ctx.saved_tensors
+        dx, dg = Fn.scalenorm_bwd(dy.contiguous(), x, g, rn, need_dg=True)
+        return dx, dg, None
+
+
+class SelfAttnQKVFn(torch.autograd.Function):
+    """qkv [B, N, 3*H*dh] (q | k | v column blocks) -> [B, N, H*dh]; dense softmax, dropout on the probabilities."""
+
+    @staticmethod
+    def forward(ctx, qkv, H, p, seed, sid):
+        qkv = qkv.contiguous()
+        B, N, D3 = qkv.shape
+        D = D3 // 3
+        dh = D // H
+        o = Fn.attn_small_fwd(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], B, N, N, H, dh, dh ** -0.5, q_batch_stride=N * D3,
+                              kv_batch_stride=N * D3, dropout_p=p, seed=seed, stream_id=sid)
+        ctx.save_for_backward(qkv)
+        ctx.cfg = (H, p, seed, sid)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        (qkv,) = ctx.saved_tensors
+        H, p, seed, sid = ctx.cfg
+        B, N, D3 = qkv.shape
+        D = D3 // 3
+        dh = D // H
+        dqkv = torch.empty_like(qkv)
+        do2 = do.contiguous().view(B * N, D)
+        base = dqkv.data_ptr()
+        check(lib().medp_attn_small_bwd(ptr(do2), D, ptr(qkv), D3, N * D3, qkv.data_ptr() + 4 * D, qkv.data_ptr() + 8 * D, D3, N * D3, base, D3,
+                                        base + 4 * D, D3, base + 8 * D, 0, N * D3, B, N, N, H, dh, dh ** -0.5, p, seed, sid, stream()),
+              "attn_small_bwd(qkv)")
+        return dqkv, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ the composition
+def _bind_stacked_bn(model):
+    """Make the V per-variable BatchNorm running statistics views of two stacked [V, H] buffers so the grouped kernel updates
+    them in place (state_dict keys and values are unchanged; re-bound if .to(device) replaced the buffers)."""
+    bns = [m[3].batch_norm for m in model.embedding_layers]
+    st = getattr(model, "_bn_stack", None)
+    ok = st is not None and all(bn.running_mean.data_ptr() == st[0][i].data_ptr() and bn.running_var.data_ptr() == st[1][i].data_ptr()
+                                for i, bn in enumerate(bns))
+    if not ok:
+        rm = torch.stack([bn.running_mean.detach() for bn in bns]).contiguous()
+        rv = torch.stack([bn.running_var.detach() for bn in bns]).contiguous()
+        for i, bn in enumerate(bns):
+            bn.running_mean = rm[i]
+            bn.running_var = rv[i]
+        model._bn_stack = (rm, rv)
+    return model._bn_stack
+
+
+def _mlp_bn(x, lin0_w, lin0_b, bn_w, bn_b, rm, rv, lin1_w, lin1_b, act_mode, batch_stats):
+    h = GLinearFn.apply(x, lin0_w, lin0_b)
+    a = ActFn.apply(h, act_mode)
+    hb = GBatchNormFn.apply(a, bn_w, bn_b, rm, rv, batch_stats)
+    return hb if lin1_w is None else GLinearFn.apply(hb, lin1_w, lin1_b)
+
+
+def encoder_training(m, x, eps, final_norm, training, seed, sid):
+    """One x_transformers-style encoder block (see oracle/xt_encoder.py) on x [B, N, D]."""
+    a, ff = m.layers[0][1], m.layers[1][1].ff
+    p = float(m.dropout) if training else 0.0
+    h = ScaleNormFn.apply(x, m.layers[0][0][0].g, eps)
+    qkv = A.linear(h, torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight], 0))
+    o = SelfAttnQKVFn.apply(qkv, m.heads, p, seed, sid)
+    x = A.linear(o, a.to_out.weight, None, residual=x)
+    h = ScaleNormFn.apply(x, m.layers[1][0][0].g, eps)
+    f = A.linear(h, ff[0][0].weight, ff[0][0].bias)
+    f = A.gelu_dropout(f, p, seed, sid + 1)
+    x = A.linear(f, ff[2].weight, ff[2].bias, residual=x)
+    if final_norm:
+        x = ScaleNormFn.apply(x, m.final_norm.g, eps)
+    return x
+
+
+def encode_training(model, x):
+    from .duett import FINAL_NORM, SCALENORM_EPS
+    xs_static, xs_feats, xs_times, _ = x
+    xs_static = xs_static.detach().to(F32).contiguous()
+    xs_feats = xs_feats.detach().to(F32).contiguous()
+    xs_times = xs_times.detach().to(F32).contiguous()
+    B, T, Fd = xs_feats.shape
+    V, E = model.d_time_series_num, model.d_embedding
+    if Fd != 2 * V + 1:
+        raise ValueError(f"xs_feats must be [B, T, 2V+1] with V={V}, got {tuple(xs_feats.shape)}")
+    if T != model.masked_transform_timesteps:
+        raise ValueError(f"this backbone was built for n_timesteps={model.masked_transform_timesteps}, got T={T}")
+    bs = bool(model.training)                                           # BatchNorm: batch statistics in train(), running in eval()
+    el = model.embedding_layers
+    rm, rv = _bind_stacked_bn(model)
+    # per-variable MLPs as ONE grouped pass (group = variable)                                  (model :45-55)
+    xin = EmbedInputsFn.apply(xs_feats, model.n_obs_embedding.weight)
+    var_out = _mlp_bn(xin, torch.stack([m[0].weight for m in el]), torch.stack([m[0].bias for m in el]),
+                      torch.stack([m[3].batch_norm.weight for m in el]), torch.stack([m[3].batch_norm.bias for m in el]), rm, rv,
+                      torch.stack([m[4].weight for m in el]), torch.stack([m[4].bias for m in el]), 0, bs)
+    te = model.tab_encoder                                                                     # (model :57)
+    tbn = te[3].batch_norm
+    tab_out = _mlp_bn(xs_static.unsqueeze(0), te[0].weight.unsqueeze(0), te[0].bias.unsqueeze(0), tbn.weight.unsqueeze(0),
+                      tbn.bias.unsqueeze(0), tbn.running_mean.unsqueeze(0), tbn.running_var.unsqueeze(0), te[4].weight.unsqueeze(0),
+                      te[4].bias.unsqueeze(0), 0, bs)[0]
+    psi = PsiAssembleFn.apply(xs_feats, var_out, tab_out, model.special_embeddings.weight)      # (model :53-66)
+    # time embedding: Linear(1,h) -> tanh -> BN -> Linear(h, tt) ; hidden padded to a multiple of 8 for the MFMA GEMM   (model :67-69)
+    tm = model.full_time_embedding
+    mbn = tm[2].batch_norm
+    hb = _mlp_bn(xs_times.reshape(1, B * T, 1), tm[0].weight.unsqueeze(0), tm[0].bias.unsqueeze(0), mbn.weight.unsqueeze(0),
+                 mbn.bias.unsqueeze(0), mbn.running_mean.unsqueeze(0), mbn.running_var.unsqueeze(0), None, None, 1, bs)[0]   # [B*T, h]
+    Hd = hb.shape[1]
+    pad = (-Hd) % 8
+    hb_p = torch.cat([hb, hb.new_zeros(hb.shape[0], pad)], 1) if pad else hb
+    w3_p = torch.cat([tm[3].weight, tm[3].weight.new_zeros(tm[3].weight.shape[0], pad)], 1) if pad else tm[3].weight
+    tt = E * (V + 1)
+    temb = A.linear(hb_p, w3_p, tm[3].bias).view(B, T, tt)
+    time_emb = torch.cat([temb, model.full_rep_embedding.weight.T.unsqueeze(0).expand(B, -1, -1)], 1)     # [B, T+1, tt]
+    if bs:
+        with torch.no_grad():
+            for bn in [m[3].batch_norm for m in el] + [tbn, mbn]:
+                bn.num_batches_tracked += 1
+    seed = A.next_seed() if (model.training and model.transformer_dropout > 0) else 0
+    T1, V1 = T + 1, V + 1
+    for l, (ev, tv) in enumerate(zip(model.event_transformers, model.time_transformers)):
+        xe = AxisSwapFn.apply(psi).view(B, V1, T1 * E)                                               # (model :80)
+        xe = AddBcastFn.apply(xe, model.full_event_embedding.weight)
+        xe = encoder_training(ev, xe, SCALENORM_EPS, FINAL_NORM, model.training, seed, 100 + 10 * l)    # (model :81)
+        xt = AxisSwapFn.apply(xe.view(B, V1, T1, E)).view(B, T1, V1 * E)
+        xt = AddBcastFn.apply(xt, time_emb)                                                            # (model :90)
+        psi = encoder_training(tv, xt, SCALENORM_EPS, FINAL_NORM, model.training, seed, 105 + 10 * l).view(B, T1, V1, E)   # (model :91)
+    return psi.flatten(2)
