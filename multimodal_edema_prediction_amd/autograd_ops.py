@@ -13,17 +13,26 @@ from .abi import check, lib, ptr, stream
 F32, BF16 = torch.float32, torch.bfloat16
 
 # ---------------------------------------------------------------------------------------------- weight caches
-_W_CACHE: dict = {}
+from torch.utils.weak import WeakIdKeyDictionary
+
+# keyed by the OWNING tensor object (the nn.Parameter; for a view such as in_proj_weight[:d], its base), so an entry dies
+# with its parameter and a recycled device address can never alias a stale copy; validated by the version counter
+_W_CACHE = WeakIdKeyDictionary()
 
 
 def _cached(t: torch.Tensor, kind: str, make):
-    key = (t.data_ptr(), tuple(t.shape), kind)
+    base = t._base if t._base is not None else t
+    sub = (t.storage_offset(), tuple(t.shape), tuple(t.stride()), kind)
     ver = t._version
-    hit = _W_CACHE.get(key)
+    slot = _W_CACHE.get(base)
+    if slot is None:
+        slot = {}
+        _W_CACHE[base] = slot
+    hit = slot.get(sub)
     if hit is not None and hit[0] == ver:
         return hit[1]
     val = make(t.detach())
-    _W_CACHE[key] = (ver, val)
+    slot[sub] = (ver, val)
     return val
 
 
