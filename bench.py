@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (weak scaling, accelerate semantics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-batch", action="store_true", help="keep batches on the host: PCIe-inclusive rate (never `value`)")
+    ap.add_argument("--eager", action="store_true", help="run the step eagerly from Python (engine.py) instead of replaying the captured HIP graph")
     args = ap.parse_args()
 
     from multimodal_edema_prediction_amd import abi, dp, engine
@@ -112,7 +113,7 @@ def main():
     loss_fn = DualPathologyLoss(torch.ones(K), None, 0.5, 0.5, 1.0).to(device)
     opt = FusedAdamW(make_param_groups(teacher, 8e-5), weight_decay=5e-2)
     sched = make_scheduler(opt, total_steps=max(args.steps + args.warmup, 1000), lr=8e-5)
-    reducer = dp.GradAllReducer([p for p in teacher.parameters() if p.requires_grad]).attach(opt) if world > 1 else None
+    reducer = dp.GradAllReducer([p for p in teacher.parameters() if p.requires_grad]).attach(opt) if (world > 1 and args.eager) else None
 
     # a small pool of distinct synthetic batches; rank r takes items r, r+N, ... of each global batch (§8e)
     n_pool = 4
@@ -122,10 +123,19 @@ def main():
         pool.append(bt if args.host_batch else engine._move_lists(bt, device))
     torch.cuda.synchronize()
 
-    def step(i):
-        out = engine.train_teacher_dual_pathology_batch(pool[i % n_pool], teacher, loss_fn, opt, device)
-        sched.step()
-        return out
+    if args.eager:
+        def step(i):
+            out = engine.train_teacher_dual_pathology_batch(pool[i % n_pool], teacher, loss_fn, opt, device)
+            sched.step()
+            return out
+    else:
+        from multimodal_edema_prediction_amd.graph_step import GraphedTeacherStep
+        gstep = GraphedTeacherStep(teacher, loss_fn, opt, pool[0], device, world=world)
+
+        def step(i):
+            out = gstep.step(pool[i % n_pool])
+            sched.step()
+            return {"loss": out["loss"].item()}          # one host read per step, like the reference's per-step logging
 
     import warnings
     warnings.filterwarnings("ignore", message=".*lr_scheduler.step.*")
@@ -175,7 +185,8 @@ def main():
                                "accumulate, random-init weights, synthetic cohort seed 1234, perceiver dropout 0.2 ON",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "gflop_per_sample": GFLOP_PER_SAMPLE, "step_mfma_fraction_of_peak": round(value * GFLOP_PER_SAMPLE / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
-                   "last_loss": round(float(last["loss"]), 5), "batch_location": "host" if args.host_batch else "hbm"},
+                   "last_loss": round(float(last["loss"]), 5), "batch_location": "host" if args.host_batch else "hbm",
+                   "execution": "eager (engine.py from Python)" if args.eager else "captured HIP graph replay (graph_step.py)"},
         "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel<128,128,1> (CXR-encoder block GEMMs: qkv/proj/fc1/fc2)",
                      "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                      "traffic": traffic, "launches": int(n_l.value),

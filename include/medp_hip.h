@@ -205,8 +205,14 @@ typedef struct {
     float lr, weight_decay;
 } MedpAdamTensor;
 int medp_adamw_chunk_elems(void);   /* elements one workgroup updates; block b handles chunk dev_block_chunk[b] of tensor dev_block_tensor[b] */
+/* step: host step count (>= 1), used when dev_step == NULL; dev_step: device counter holding the step (graph replay) */
 int medp_adamw_multi(const MedpAdamTensor* dev_descs, const int* dev_block_tensor, const int* dev_block_chunk, int n_blocks,
-                     float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+                     float beta1, float beta2, float eps, int step, const unsigned* dev_step, float grad_scale, void* stream);
+
+/* ---- HIP-graph support: state that must change between replays lives in device memory --------------------------------
+ * medp_rng_set_epoch_ptr: device uint32 mixed into every dropout seed (NULL = off); medp_counter_advance: *c += 1 */
+int medp_rng_set_epoch_ptr(const unsigned* dev_ptr);
+int medp_counter_advance(unsigned* dev_counter, void* stream);
 
 /* ---- DuETT embedding stage in TRAINING form (student KD path; BatchNorm batch statistics, gradients everywhere) ------
  * grouped tiny layers, group = variable: x [G,R,K], W [G,N,K], b [G,N]   (duett/duett.py:24-39,84-86,124-125,151-157) */

@@ -105,7 +105,9 @@ SIGNATURES = {
     "medp_axis_swap": (I, [P, P, I, I, I, I, P]),
     "medp_add_bcast": (I, [P, P, P, LL, I, I, P]),
     "medp_adamw_chunk_elems": (I, []),
-    "medp_adamw_multi": (I, [P, P, P, I, F, F, F, I, F, P]),
+    "medp_adamw_multi": (I, [P, P, P, I, F, F, F, I, P, F, P]),
+    "medp_rng_set_epoch_ptr": (I, [P]),
+    "medp_counter_advance": (I, [P, P]),
 }
 
 _lib = None

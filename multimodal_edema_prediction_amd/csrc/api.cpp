@@ -16,3 +16,12 @@ void medp_set_error(const char* fmt, ...) {
 extern "C" const char* medp_last_error(void) { return g_err; }
 extern "C" int medp_version(void) { return 1; }
 extern "C" const char* medp_arch(void) { return "gfx950"; }
+
+// ---- RNG epoch (see common.h) and a one-word device counter ------------------------------------------------------------
+#include <stdint.h>
+static const uint32_t* g_rng_epoch = nullptr;
+const uint32_t* medp_rng_epoch_ptr() { return g_rng_epoch; }
+extern "C" int medp_rng_set_epoch_ptr(const unsigned* dev_ptr) {
+    g_rng_epoch = dev_ptr;
+    return 0;
+}

@@ -28,6 +28,7 @@ struct SmallAttnParams {
     int B, Lq, Lk, H, dh;
     float scale, drop_p, inv_keep;
     uint32_t seed, stream_id;
+    const uint32_t* epoch;
 };
 
 // scores + softmax for one query row; returns p (post-softmax, pre-dropout) per owned key in pj[], writes nothing
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(const SmallAttnPara
             const int j = lane + 64 * i;
             if (j < p.Lk) {
                 float w = pj[i];
-                if (p.drop_p > 0.f) w *= dropout_scale(p.seed, p.stream_id, ((uint32_t)(b * p.H + h) * p.Lq + qi) * p.Lk + j, p.drop_p, p.inv_keep);
+                if (p.drop_p > 0.f) w *= dropout_scale(medp_mix_epoch(p.seed, p.epoch), p.stream_id, ((uint32_t)(b * p.H + h) * p.Lq + qi) * p.Lk + j, p.drop_p, p.inv_keep);
                 sp[j] = w;
                 if (attn_avg) atomicAdd(attn_avg + ((size_t)b * p.Lq + qi) * p.Lk + j, w / (float)p.H);
             }
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const SmallAttnPara
                 if (j < p.Lk) {
                     const float* vr = vbase + (size_t)j * p.ldv;
                     for (int d = 0; d < p.dh; ++d) dp += dor[d] * vr[d];
-                    if (p.drop_p > 0.f) msk = dropout_scale(p.seed, p.stream_id, ((uint32_t)(b * p.H + h) * p.Lq + qi) * p.Lk + j, p.drop_p, p.inv_keep);
+                    if (p.drop_p > 0.f) msk = dropout_scale(medp_mix_epoch(p.seed, p.epoch), p.stream_id, ((uint32_t)(b * p.H + h) * p.Lq + qi) * p.Lk + j, p.drop_p, p.inv_keep);
                     dp *= msk;
                     sP[ql * p.Lk + j] = pj[i] * msk;          // dropped-out weights multiply V in forward
                 }
@@ -196,7 +197,7 @@ int check(const SmallAttnParams& p) {
 extern "C" int medp_attn_small_fwd(const float* q, int ldq, long long q_batch_stride, const float* k, const float* v, int ldkv,
                                    long long kv_batch_stride, void* o, int ldo, int o_bf16, float* attn_avg, int B, int Lq, int Lk,
                                    int H, int dh, float scale, float dropout_p, unsigned seed, unsigned stream_id, void* stream) {
-    SmallAttnParams p{q, k, v, ldq, ldkv, ldkv, q_batch_stride, kv_batch_stride, B, Lq, Lk, H, dh, scale, dropout_p, 1.0f / (1.0f - dropout_p), seed, stream_id};
+    SmallAttnParams p{q, k, v, ldq, ldkv, ldkv, q_batch_stride, kv_batch_stride, B, Lq, Lk, H, dh, scale, dropout_p, 1.0f / (1.0f - dropout_p), seed, stream_id, medp_rng_epoch_ptr()};
     MEDP_TRY(check(p));
     MEDP_CHECK_ARG(o, "attn_small_fwd: null output");
     const size_t lds = (size_t)(4 * Lk + 4 * dh) * sizeof(float);
@@ -217,7 +218,7 @@ extern "C" int medp_attn_small_bwd(const float* dout, int lddo, const float* q, 
                                    float scale, float dropout_p, unsigned seed, unsigned stream_id, void* stream) {
     const int lddv = lddk;
     (void)lddkv_unused;
-    SmallAttnParams p{q, k, v, ldq, ldkv, ldkv, q_batch_stride, kv_batch_stride, B, Lq, Lk, H, dh, scale, dropout_p, 1.0f / (1.0f - dropout_p), seed, stream_id};
+    SmallAttnParams p{q, k, v, ldq, ldkv, ldkv, q_batch_stride, kv_batch_stride, B, Lq, Lk, H, dh, scale, dropout_p, 1.0f / (1.0f - dropout_p), seed, stream_id, medp_rng_epoch_ptr()};
     MEDP_TRY(check(p));
     MEDP_CHECK_ARG(dout && dq && dk && dv, "attn_small_bwd: null gradient buffer");
     const size_t lds = (size_t)(2 * QCH * Lk + 2 * QCH * dh) * sizeof(float);

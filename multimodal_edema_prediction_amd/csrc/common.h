@@ -40,6 +40,11 @@ int medp_gemm_bf16_nt_tagged(int tag, const void* A, const void* W, void* C, int
                              const float* bias, const float* scale, const float* residual, int ldr, int act, int out_bf16,
                              void* stream);
 
+// device pointer (may be null) to a uint32 "RNG epoch" mixed into every dropout seed: lets a captured HIP graph draw a
+// fresh mask on every replay although the per-call seeds are baked into the graph (set by medp_rng_set_epoch_ptr)
+const uint32_t* medp_rng_epoch_ptr();
+__device__ __forceinline__ uint32_t medp_mix_epoch(uint32_t seed, const uint32_t* epoch) { return epoch ? seed + epoch[0] * 0x9E3779B9u : seed; }
+
 // ---- bf16 <-> f32 --------------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 // round-to-nearest-even; the plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN a NaN

@@ -10,7 +10,8 @@ inline int grid_for(size_t work_items) { return (int)min((size_t)2048, max((size
 
 // y = dropout(gelu(x))                        (nn.GELU -> nn.Dropout, model :755, :573)
 __global__ __launch_bounds__(256) void gelu_dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, float p,
-                                                               float inv_keep, uint32_t seed, uint32_t sid) {
+                                                               float inv_keep, uint32_t seed0, uint32_t sid, const uint32_t* __restrict__ epoch) {
+    const uint32_t seed = medp_mix_epoch(seed0, epoch);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         float v = gelu_erf(x[i]);
         if (p > 0.f) v *= dropout_scale(seed, sid, (uint32_t)i, p, inv_keep);
@@ -20,7 +21,8 @@ __global__ __launch_bounds__(256) void gelu_dropout_fwd_kernel(const float* __re
 // dx = dy * mask * gelu'(x)
 __global__ __launch_bounds__(256) void gelu_dropout_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                float* __restrict__ dx, size_t n, float p, float inv_keep,
-                                                               uint32_t seed, uint32_t sid) {
+                                                               uint32_t seed0, uint32_t sid, const uint32_t* __restrict__ epoch) {
+    const uint32_t seed = medp_mix_epoch(seed0, epoch);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         float g = dy[i] * gelu_erf_grad(x[i]);
         if (p > 0.f) g *= dropout_scale(seed, sid, (uint32_t)i, p, inv_keep);
@@ -29,8 +31,9 @@ __global__ __launch_bounds__(256) void gelu_dropout_bwd_kernel(const float* __re
 }
 // out = res + dropout(y)  (fwd, res may be null)   |   dy = dout * mask  (bwd: res == nullptr, y = dout)
 __global__ __launch_bounds__(256) void dropout_add_kernel(const float* __restrict__ y, const float* __restrict__ res,
-                                                          float* __restrict__ out, size_t n, float p, float inv_keep, uint32_t seed,
-                                                          uint32_t sid) {
+                                                          float* __restrict__ out, size_t n, float p, float inv_keep, uint32_t seed0,
+                                                          uint32_t sid, const uint32_t* __restrict__ epoch) {
+    const uint32_t seed = medp_mix_epoch(seed0, epoch);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         float v = y[i];
         if (p > 0.f) v *= dropout_scale(seed, sid, (uint32_t)i, p, inv_keep);
@@ -308,21 +311,21 @@ __global__ __launch_bounds__(256) void masked_bce_kernel(const float* __restrict
 
 extern "C" int medp_gelu_dropout_fwd(const float* x, float* y, long long n, float p, unsigned seed, unsigned stream_id, void* stream) {
     MEDP_CHECK_ARG(x && y && n > 0 && p >= 0.f && p < 1.f, "gelu_dropout_fwd: bad argument");
-    gelu_dropout_fwd_kernel<<<grid_for((size_t)n), 256, 0, (hipStream_t)stream>>>(x, y, (size_t)n, p, 1.f / (1.f - p), seed, stream_id);
+    gelu_dropout_fwd_kernel<<<grid_for((size_t)n), 256, 0, (hipStream_t)stream>>>(x, y, (size_t)n, p, 1.f / (1.f - p), seed, stream_id, medp_rng_epoch_ptr());
     MEDP_LAUNCH_CHECK("medp_gelu_dropout_fwd");
     return 0;
 }
 extern "C" int medp_gelu_dropout_bwd(const float* dy, const float* x, float* dx, long long n, float p, unsigned seed,
                                      unsigned stream_id, void* stream) {
     MEDP_CHECK_ARG(dy && x && dx && n > 0 && p >= 0.f && p < 1.f, "gelu_dropout_bwd: bad argument");
-    gelu_dropout_bwd_kernel<<<grid_for((size_t)n), 256, 0, (hipStream_t)stream>>>(dy, x, dx, (size_t)n, p, 1.f / (1.f - p), seed, stream_id);
+    gelu_dropout_bwd_kernel<<<grid_for((size_t)n), 256, 0, (hipStream_t)stream>>>(dy, x, dx, (size_t)n, p, 1.f / (1.f - p), seed, stream_id, medp_rng_epoch_ptr());
     MEDP_LAUNCH_CHECK("medp_gelu_dropout_bwd");
     return 0;
 }
 extern "C" int medp_dropout_add(const float* y, const float* residual, float* out, long long n, float p, unsigned seed,
                                 unsigned stream_id, void* stream) {
     MEDP_CHECK_ARG(y && out && n > 0 && p >= 0.f && p < 1.f, "dropout_add: bad argument");
-    dropout_add_kernel<<<grid_for((size_t)n), 256, 0, (hipStream_t)stream>>>(y, residual, out, (size_t)n, p, 1.f / (1.f - p), seed, stream_id);
+    dropout_add_kernel<<<grid_for((size_t)n), 256, 0, (hipStream_t)stream>>>(y, residual, out, (size_t)n, p, 1.f / (1.f - p), seed, stream_id, medp_rng_epoch_ptr());
     MEDP_LAUNCH_CHECK("medp_dropout_add");
     return 0;
 }
@@ -402,5 +405,15 @@ extern "C" int medp_masked_bce_global(const float* logits, const float* y, const
     MEDP_CHECK_ARG(logits && y && mask && out && n > 0, "masked_bce_global: bad argument");
     masked_bce_kernel<<<1, 256, 0, (hipStream_t)stream>>>(logits, y, mask, out, g, n);
     MEDP_LAUNCH_CHECK("medp_masked_bce_global");
+    return 0;
+}
+
+namespace {
+__global__ void counter_advance_kernel(unsigned* c) { c[0] += 1u; }
+}
+extern "C" int medp_counter_advance(unsigned* dev_counter, void* stream) {
+    MEDP_CHECK_ARG(dev_counter, "counter_advance: null pointer");
+    counter_advance_kernel<<<1, 1, 0, (hipStream_t)stream>>>(dev_counter);
+    MEDP_LAUNCH_CHECK("medp_counter_advance");
     return 0;
 }

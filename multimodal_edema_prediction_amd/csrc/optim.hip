@@ -11,7 +11,15 @@ constexpr int CHUNK = 4096;   // elements per block (256 threads x 4 float4)
 
 __global__ __launch_bounds__(256) void adamw_multi_kernel(const MedpAdamTensor* __restrict__ descs, const int* __restrict__ blk_tensor,
                                                           const int* __restrict__ blk_chunk, float beta1, float beta2, float eps,
-                                                          float bc1, float bc2_sqrt, float grad_scale) {
+                                                          float bc1_host, float bc2_sqrt_host, float grad_scale,
+                                                          const unsigned* __restrict__ dev_step) {
+    // bias corrections from a DEVICE step counter when given (graph replay: the host step count is frozen in the graph)
+    float bc1 = bc1_host, bc2_sqrt = bc2_sqrt_host;
+    if (dev_step) {
+        const float st = (float)dev_step[0];
+        bc1 = 1.f - powf(beta1, st);
+        bc2_sqrt = sqrtf(1.f - powf(beta2, st));
+    }
     const MedpAdamTensor d = descs[blk_tensor[blockIdx.x]];
     const long long base = (long long)blk_chunk[blockIdx.x] * CHUNK;
     const float lr = d.lr, decay = 1.f - d.lr * d.weight_decay, step_size = d.lr / bc1;
@@ -52,11 +60,11 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const MedpAdamTensor* 
 extern "C" int medp_adamw_chunk_elems(void) { return CHUNK; }
 
 extern "C" int medp_adamw_multi(const MedpAdamTensor* dev_descs, const int* dev_block_tensor, const int* dev_block_chunk, int n_blocks,
-                                float beta1, float beta2, float eps, int step, float grad_scale, void* stream) {
-    MEDP_CHECK_ARG(dev_descs && dev_block_tensor && dev_block_chunk && n_blocks > 0 && step >= 1, "adamw_multi: bad argument");
+                                float beta1, float beta2, float eps, int step, const unsigned* dev_step, float grad_scale, void* stream) {
+    MEDP_CHECK_ARG(dev_descs && dev_block_tensor && dev_block_chunk && n_blocks > 0 && (step >= 1 || dev_step), "adamw_multi: bad argument");
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
-    adamw_multi_kernel<<<n_blocks, 256, 0, (hipStream_t)stream>>>(dev_descs, dev_block_tensor, dev_block_chunk, beta1, beta2, eps, bc1, bc2s, grad_scale);
+    adamw_multi_kernel<<<n_blocks, 256, 0, (hipStream_t)stream>>>(dev_descs, dev_block_tensor, dev_block_chunk, beta1, beta2, eps, bc1, bc2s, grad_scale, dev_step);
     MEDP_LAUNCH_CHECK("medp_adamw_multi");
     return 0;
 }

@@ -1,0 +1,123 @@
+"""Whole-step HIP graph: the MI355X-first way to run the training step (SURVEY.md §7 "HIP streams and graphs instead of a
+tracing compiler").  The eager step of engine.py issues ~700 launches from Python and is host-bound; here the complete
+`train_teacher_dual_pathology_batch` arithmetic — both frozen encoders, the fusion head forward, DualPathologyLoss, the
+backward of every trainable parameter and the fused AdamW update — is captured ONCE into a hipGraph and replayed per
+step.  Everything that must differ between replays lives in device memory: the input batch (static buffers), the dropout
+RNG epoch (`medp_rng_set_epoch_ptr`), the optimiser step count (`FusedAdamW.dev_step`) and the per-group learning rates
+(the descriptor table is re-uploaded from pinned host memory by a captured memcpy node).
+
+N > 1: forward+backward are one graph accumulating into a flat fp32 gradient arena, the arena is all-reduced by RCCL
+between the two replays (one collective, 14.8 MB), and the optimiser is a second graph.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import engine
+from .abi import check, lib, ptr, stream
+
+
+class GraphedTeacherStep:
+    def __init__(self, teacher, loss_fn, optimizer, example_batch: dict, device, world: int = 1, group=None, warmup: int = 3):
+        self.teacher, self.loss_fn, self.opt, self.device, self.world, self.group = teacher, loss_fn, optimizer, device, world, group
+        b = engine._move_lists(example_batch, device)
+        # static input buffers; the per-sample tuples the model interface wants are views into the stacked buffers
+        self.x_ts = torch.stack(b["x_ts"]).contiguous()
+        self.x_static = torch.stack(b["x_static"]).contiguous()
+        self.bin_ends = torch.stack(b["bin_ends"]).contiguous()
+        self.pixels = b["pixel_values"].clone()
+        self.y_multi = b["y_multi"].clone().float()
+        self.y_mask = b["y_multi_mask"].clone().float()
+        self.epoch = torch.zeros(1, dtype=torch.int32, device=device)
+        self.opt.dev_step = torch.zeros(1, dtype=torch.int32, device=device)
+        check(lib().medp_rng_set_epoch_ptr(ptr(self.epoch)), "rng_set_epoch_ptr")
+        self.params = [p for g in optimizer.param_groups for p in g["params"] if p.requires_grad]
+        self.flat_grad = None
+        if world > 1:
+            n = sum(p.numel() for p in self.params)
+            self.flat_grad = torch.zeros(n, dtype=torch.float32, device=device)
+        engine._set_train_with_frozen_eval(teacher)
+        # warm-up on a side stream (allocator pools, lazy workspaces, optimiser state), as torch.cuda.graphs requires
+        s = torch.cuda.Stream(device=device)
+        s.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self._zero_grads()
+                self._advance()
+                self._fwd_bwd()
+                self._allreduce()
+                self.opt.step()
+        torch.cuda.current_stream(device).wait_stream(s)
+        torch.cuda.synchronize(device)
+        self._zero_grads()
+        self.g_fb = torch.cuda.CUDAGraph()
+        if world == 1:
+            with torch.cuda.graph(self.g_fb):
+                self._advance()
+                self.out = self._fwd_bwd()
+                self.opt.step()
+            self.g_opt = None
+        else:
+            with torch.cuda.graph(self.g_fb):
+                self.flat_grad.zero_()
+                self._advance()
+                self.out = self._fwd_bwd()
+            self.g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_opt):
+                self.opt.step()
+        torch.cuda.synchronize(device)
+        self.opt._step = int(self.opt.dev_step.item())      # capture ran opt.step() on the host without executing it
+
+    # ---- pieces ---------------------------------------------------------------------------------------------------------
+    def _zero_grads(self):
+        if self.flat_grad is None:
+            self.opt.zero_grad(set_to_none=True)
+        else:
+            off = 0
+            self.flat_grad.zero_()
+            for p in self.params:                  # gradients accumulate straight into the flat arena (no packing step)
+                p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+                off += p.numel()
+
+    def _advance(self):
+        check(lib().medp_counter_advance(ptr(self.epoch), stream()), "counter_advance")
+        check(lib().medp_counter_advance(ptr(self.opt.dev_step), stream()), "counter_advance")
+
+    def _fwd_bwd(self):
+        B = self.x_ts.shape[0]
+        out = self.teacher(tuple(self.x_ts[i] for i in range(B)), tuple(self.x_static[i] for i in range(B)),
+                           tuple(self.bin_ends[i] for i in range(B)), self.pixels)
+        losses = self.loss_fn(out["img_logits"], out["ts_logits"], out["fusion_logits"], self.y_multi, self.y_mask)
+        losses["total"].backward()
+        return {"loss": losses["total"].detach(), "img_total": losses["img_total"], "ts_total": losses["ts_total"],
+                "fus_total": losses["fus_total"], "fusion_logits": out["fusion_logits"].detach(), "main_logit": out["main_logit"].detach()}
+
+    def _allreduce(self):
+        if self.world > 1:
+            op = dist.ReduceOp.AVG if dist.get_backend(self.group) == "nccl" else dist.ReduceOp.SUM
+            dist.all_reduce(self.flat_grad, op=op, group=self.group)
+            if op == dist.ReduceOp.SUM:
+                self.flat_grad.div_(self.world)
+
+    # ---- one training step --------------------------------------------------------------------------------------------------
+    def load_batch(self, batch: dict) -> None:
+        """Copy a batch (host or device) into the static input buffers (async on the current stream)."""
+        self.x_ts.copy_(torch.stack(tuple(batch["x_ts"])), non_blocking=True)
+        self.x_static.copy_(torch.stack(tuple(batch["x_static"])), non_blocking=True)
+        self.bin_ends.copy_(torch.stack(tuple(batch["bin_ends"])), non_blocking=True)
+        self.pixels.copy_(batch["pixel_values"], non_blocking=True)
+        self.y_multi.copy_(batch["y_multi"], non_blocking=True)
+        self.y_mask.copy_(batch["y_multi_mask"], non_blocking=True)
+
+    def step(self, batch: dict | None = None) -> dict:
+        """Replay the captured step; returns device tensors (no host sync — read them with .item() when needed)."""
+        if batch is not None:
+            self.load_batch(batch)
+        self.opt.refresh_lrs()                       # learning rates of this step (scheduler) -> pinned descriptor table
+        self.g_fb.replay()
+        if self.g_opt is not None:
+            self._allreduce()
+            self.g_opt.replay()
+        self.opt.note_external_step()
+        return self.out

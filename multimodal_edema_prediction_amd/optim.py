@@ -56,6 +56,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._map_key = None
         self._blk_t = self._blk_c = self._descs_dev = None
         self._descs_host = None
+        self.dev_step = None          # optional device uint32 step counter (graph replay); advanced by the owner of the graph
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -96,6 +97,7 @@ class FusedAdamW(torch.optim.Optimizer):
             self._descs_host = torch.empty(len(key) * ctypes.sizeof(MedpAdamTensor), dtype=torch.uint8).pin_memory()
             self._descs_dev = torch.empty_like(self._descs_host, device=dev)
             self._map_key = key
+        self._entries = entries
         arr = (MedpAdamTensor * len(entries)).from_address(self._descs_host.data_ptr())
         for i, (p, st, lr, wd) in enumerate(entries):
             a = arr[i]
@@ -103,8 +105,20 @@ class FusedAdamW(torch.optim.Optimizer):
             a.numel, a.lr, a.weight_decay = p.numel(), lr, wd
         self._descs_dev.copy_(self._descs_host, non_blocking=True)
         check(lib().medp_adamw_multi(ptr(self._descs_dev), ptr(self._blk_t), ptr(self._blk_c), self._blk_t.numel(), betas[0], betas[1],
-                                     eps, self._step, 1.0, stream()), "adamw_multi")
+                                     eps, self._step, ptr(self.dev_step), 1.0, stream()), "adamw_multi")
         # the kernel wrote the parameters behind torch's back: bump their version counters (host-side only, no launch) so
         # autograd's saved-tensor checks and the bf16 weight caches keyed on `_version` see the update
         torch.autograd.graph.increment_version([p for p, *_ in entries])
         return loss
+
+    # ---- graph-replay support: the captured step re-uploads the pinned descriptor table; only the lr fields change ----
+    def refresh_lrs(self) -> None:
+        lr_of = {id(p): float(g["lr"]) for g in self.param_groups for p in g["params"]}
+        arr = (MedpAdamTensor * len(self._entries)).from_address(self._descs_host.data_ptr())
+        for i, (p, *_rest) in enumerate(self._entries):
+            arr[i].lr = lr_of[id(p)]
+
+    def note_external_step(self) -> None:
+        """A captured replay updated the parameters: advance the host step count and the parameters' version counters."""
+        self._step += 1
+        torch.autograd.graph.increment_version([p for p, *_ in self._entries])

@@ -251,3 +251,23 @@ def test_linear_probe_cfg2():
     gw = m.classifier[1].weight.grad.cpu()
     assert float((gw - W.grad).norm() / W.grad.norm()) < 0.05
     assert maxerr(m.classifier[1].bias.grad, bb.grad) < 1e-3
+
+
+def test_graphed_step_equals_eager_step(tbatch):
+    """The captured HIP-graph step (graph_step.py) must do exactly the eager engine step's arithmetic (dropout off)."""
+    from multimodal_edema_prediction_amd.graph_step import GraphedTeacherStep
+    from multimodal_edema_prediction_amd.optim import make_param_groups
+    loss_fn = DualPathologyLoss(torch.ones(K), None, 0.5, 0.5, 1.0).to(DEV)
+    te = build_teacher()
+    oe = FusedAdamW(make_param_groups(te, 8e-5), weight_decay=5e-2)
+    eager_losses = [engine.train_teacher_dual_pathology_batch(tbatch, te, loss_fn, oe, torch.device(DEV))["loss"] for _ in range(6)]
+    tg = build_teacher()
+    og = FusedAdamW(make_param_groups(tg, 8e-5), weight_decay=5e-2)
+    gs = GraphedTeacherStep(tg, loss_fn, og, tbatch, torch.device(DEV), warmup=3)       # 3 real steps happen during warm-up
+    graph_losses = [float(gs.step(tbatch)["loss"].item()) for _ in range(3)]
+    # eager steps 4..6 vs the three replays (steps 4..6 of the graphed run)
+    np.testing.assert_allclose(graph_losses, eager_losses[3:], rtol=1e-5, atol=1e-6)
+    for (k, a), (_, b) in zip(te.named_parameters(), tg.named_parameters()):
+        if a.requires_grad:
+            assert float((a - b).abs().max()) <= 1e-6, k
+    assert og._step == oe._step == 6
