@@ -130,7 +130,10 @@ def main():
             return out
     else:
         from multimodal_edema_prediction_amd.graph_step import GraphedTeacherStep
-        gstep = GraphedTeacherStep(teacher, loss_fn, opt, pool[0], device, world=world)
+        # arm the live GEMM timing right before capture: the HIP events around every CXR-encoder block GEMM become
+        # event-record nodes of the graph, re-recorded by every replay; after the timed region they hold the last step's times
+        gstep = GraphedTeacherStep(teacher, loss_fn, opt, pool[0], device, world=world,
+                                   before_capture=lambda: abi.lib().medp_gemm_profile_enable(1))
 
         def step(i):
             out = gstep.step(pool[i % n_pool])
@@ -146,7 +149,8 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
-    L.medp_gemm_profile_enable(1)
+    if args.eager:
+        L.medp_gemm_profile_enable(1)
     t0 = time.perf_counter()
     for i in range(args.steps):
         last = step(args.warmup + i)
@@ -154,7 +158,6 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
-    L.medp_gemm_profile_enable(0) if False else None
     ms, n_l, fl = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
     abi.check(L.medp_gemm_profile_collect(ctypes.byref(ms), ctypes.byref(n_l), ctypes.byref(fl)), "gemm_profile_collect")
     L.medp_gemm_profile_enable(0)

@@ -3,7 +3,7 @@ tracing compiler").  The eager step of engine.py issues ~700 launches from Pytho
 `train_teacher_dual_pathology_batch` arithmetic — both frozen encoders, the fusion head forward, DualPathologyLoss, the
 backward of every trainable parameter and the fused AdamW update — is captured ONCE into a hipGraph and replayed per
 step.  Everything that must differ between replays lives in device memory: the input batch (static buffers), the dropout
-RNG epoch (`medp_rng_set_epoch_ptr`), the optimiser step count (`FusedAdamW.dev_step`) and the per-group learning rates
+RNG epoch (`medp_rng_set_epoch_ptr`), the optimiser step count (`FusedAdamW.dev_step`, advanced by the captured optimiser itself) and the per-group learning rates
 (the descriptor table is re-uploaded from pinned host memory by a captured memcpy node).
 
 N > 1: forward+backward are one graph accumulating into a flat fp32 gradient arena, the arena is all-reduced by RCCL
@@ -19,7 +19,8 @@ from .abi import check, lib, ptr, stream
 
 
 class GraphedTeacherStep:
-    def __init__(self, teacher, loss_fn, optimizer, example_batch: dict, device, world: int = 1, group=None, warmup: int = 3):
+    def __init__(self, teacher, loss_fn, optimizer, example_batch: dict, device, world: int = 1, group=None, warmup: int = 3,
+                 split: bool = False, before_capture=None):
         self.teacher, self.loss_fn, self.opt, self.device, self.world, self.group = teacher, loss_fn, optimizer, device, world, group
         b = engine._move_lists(example_batch, device)
         # static input buffers; the per-sample tuples the model interface wants are views into the stacked buffers
@@ -30,11 +31,11 @@ class GraphedTeacherStep:
         self.y_multi = b["y_multi"].clone().float()
         self.y_mask = b["y_multi_mask"].clone().float()
         self.epoch = torch.zeros(1, dtype=torch.int32, device=device)
-        self.opt.dev_step = torch.zeros(1, dtype=torch.int32, device=device)
         check(lib().medp_rng_set_epoch_ptr(ptr(self.epoch)), "rng_set_epoch_ptr")
         self.params = [p for g in optimizer.param_groups for p in g["params"] if p.requires_grad]
         self.flat_grad = None
-        if world > 1:
+        self.split = split or world > 1
+        if self.split:
             n = sum(p.numel() for p in self.params)
             self.flat_grad = torch.zeros(n, dtype=torch.float32, device=device)
         engine._set_train_with_frozen_eval(teacher)
@@ -51,8 +52,10 @@ class GraphedTeacherStep:
         torch.cuda.current_stream(device).wait_stream(s)
         torch.cuda.synchronize(device)
         self._zero_grads()
+        if before_capture is not None:
+            before_capture()                         # e.g. arm the GEMM timing events so they become nodes of the graph
         self.g_fb = torch.cuda.CUDAGraph()
-        if world == 1:
+        if not self.split:
             with torch.cuda.graph(self.g_fb):
                 self._advance()
                 self.out = self._fwd_bwd()
@@ -82,7 +85,6 @@ class GraphedTeacherStep:
 
     def _advance(self):
         check(lib().medp_counter_advance(ptr(self.epoch), stream()), "counter_advance")
-        check(lib().medp_counter_advance(ptr(self.opt.dev_step), stream()), "counter_advance")
 
     def _fwd_bwd(self):
         B = self.x_ts.shape[0]

@@ -56,7 +56,8 @@ class FusedAdamW(torch.optim.Optimizer):
         self._map_key = None
         self._blk_t = self._blk_c = self._descs_dev = None
         self._descs_host = None
-        self.dev_step = None          # optional device uint32 step counter (graph replay); advanced by the owner of the graph
+        self.dev_step = None          # device uint32 step counter: bias corrections are computed ON DEVICE from it, so the
+                                      # eager step and a captured-graph replay run bit-identical arithmetic
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -104,6 +105,9 @@ class FusedAdamW(torch.optim.Optimizer):
             a.param, a.grad, a.exp_avg, a.exp_avg_sq = p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
             a.numel, a.lr, a.weight_decay = p.numel(), lr, wd
         self._descs_dev.copy_(self._descs_host, non_blocking=True)
+        if self.dev_step is None or self.dev_step.device != dev:
+            self.dev_step = torch.full((1,), self._step - 1, dtype=torch.int32, device=dev)
+        check(lib().medp_counter_advance(ptr(self.dev_step), stream()), "counter_advance")
         check(lib().medp_adamw_multi(ptr(self._descs_dev), ptr(self._blk_t), ptr(self._blk_c), self._blk_t.numel(), betas[0], betas[1],
                                      eps, self._step, ptr(self.dev_step), 1.0, stream()), "adamw_multi")
         # the kernel wrote the parameters behind torch's back: bump their version counters (host-side only, no launch) so
