@@ -96,7 +96,7 @@ class GraphedTeacherStep:
                 "fus_total": losses["fus_total"], "fusion_logits": out["fusion_logits"].detach(), "main_logit": out["main_logit"].detach()}
 
     def _allreduce(self):
-        if self.world > 1:
+        if self.world > 1 and dist.is_initialized():
             op = dist.ReduceOp.AVG if dist.get_backend(self.group) == "nccl" else dist.ReduceOp.SUM
             dist.all_reduce(self.flat_grad, op=op, group=self.group)
             if op == dist.ReduceOp.SUM:
