@@ -141,7 +141,7 @@ typedef struct {
     const void* n_obs_table;      /* fp32 [n_obs_rows] (n_obs_embedding.weight[:,0]) */
     const void *tab_w0, *tab_b0, *tab_bn_scale, *tab_bn_shift, *tab_w4, *tab_b4;   /* tab_encoder (duett.py:124-125) */
     const void* special;          /* fp32 [8, E] special_embeddings */
-    const void *time_w0, *time_b0, *time_bn_scale, *time_bn_shift, *time_w3, *time_b3;   /* full_time_embedding = cve (duett.py:151-157) */
+    const void *time_w0, *time_b0, *time_bn_scale, *time_bn_shift, *time_w3t, *time_b3;   /* full_time_embedding = cve (duett.py:151-157); time_w3t = weight of the last Linear TRANSPOSED, fp32 [h, tt] */
     const void* rep_embedding;    /* fp32 [tt_dim]  full_rep_embedding.weight[:,0] */
     const void* event_embedding;  /* fp32 [V+1, et_dim] full_event_embedding.weight */
     const MedpEncoderWeights* event_enc;   /* HOST arrays of n_layers entries */

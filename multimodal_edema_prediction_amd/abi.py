@@ -40,7 +40,7 @@ class MedpDuettWeights(ctypes.Structure):
                 + [("norm_eps", F)]
                 + [(n, P) for n in ("emb_w0", "emb_b0", "emb_bn_scale", "emb_bn_shift", "emb_w4", "emb_b4", "n_obs_table",
                                     "tab_w0", "tab_b0", "tab_bn_scale", "tab_bn_shift", "tab_w4", "tab_b4", "special",
-                                    "time_w0", "time_b0", "time_bn_scale", "time_bn_shift", "time_w3", "time_b3",
+                                    "time_w0", "time_b0", "time_bn_scale", "time_bn_shift", "time_w3t", "time_b3",
                                     "rep_embedding", "event_embedding")]
                 + [("event_enc", ctypes.POINTER(MedpEncoderWeights)), ("time_enc", ctypes.POINTER(MedpEncoderWeights))])
 

@@ -119,10 +119,10 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const float* __restrict
     const float tv = times[(size_t)b * T + t];
     for (int j = threadIdx.x; j < Hd; j += 256) hid[j] = tanhf(w0[j] * tv + b0[j]) * s[j] + sh[j];
     __syncthreads();
+    // w3t is the TRANSPOSED weight [Hd][tt]: consecutive threads read consecutive addresses
     for (int c = threadIdx.x; c < tt; c += 256) {
         float a = b3[c];
-        const float* wr = w3 + (size_t)c * Hd;
-        for (int j = 0; j < Hd; ++j) a += wr[j] * hid[j];
+        for (int j = 0; j < Hd; ++j) a += w3[(size_t)j * tt + c] * hid[j];
         o[c] = a;
     }
 }
@@ -238,7 +238,7 @@ extern "C" int medp_duett_encode(const MedpDuettWeights* w, const float* xs_stat
     }
     time_embed_kernel<<<B * T1, 256, w->d_hidden_time * sizeof(float), s>>>(
         xs_times, (const float*)w->time_w0, (const float*)w->time_b0, (const float*)w->time_bn_scale, (const float*)w->time_bn_shift,
-        (const float*)w->time_w3, (const float*)w->time_b3, (const float*)w->rep_embedding, temb, B, T, w->d_hidden_time, tt);
+        (const float*)w->time_w3t, (const float*)w->time_b3, (const float*)w->rep_embedding, temb, B, T, w->d_hidden_time, tt);
     MEDP_LAUNCH_CHECK("duett time_embed");
 
     const int E4 = E / 4;

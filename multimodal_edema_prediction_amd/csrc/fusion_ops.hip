@@ -51,30 +51,32 @@ __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float* __restrict
     a = wave_sum(a);
     if (lane == 0) y[row] = a + (b ? b[0] : 0.f);
 }
-// dx[m,c] = dy[m]*w[c] ; dw[c] = sum_m dy[m]*x[m,c] ; db = sum_m dy[m]       single block (rows <= a few thousand)
+// dx[m,c] = dy[m]*w[c] ; dw[c] = sum_m dy[m]*x[m,c] ; db = sum_m dy[m]
+// grid = ceil(D/64) blocks of 64 columns x 4 row-lanes (block 0 also writes db); dx written by all blocks, row-strided
 __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, int ldx,
                                                          const float* __restrict__ w, float* __restrict__ dx, float* __restrict__ dw,
                                                          float* __restrict__ db, int rows, int D) {
-    __shared__ float red[256];
-    for (size_t i = threadIdx.x; i < (size_t)rows * D; i += 256) {
-        const int m = (int)(i / D), c = (int)(i % D);
-        dx[(size_t)m * D + c] = dy[m] * w[c];
-    }
-    for (int c = threadIdx.x; c < D; c += 256) {
-        float a = 0.f;
-        for (int m = 0; m < rows; ++m) a += dy[m] * x[(size_t)m * ldx + c];
-        dw[c] = a;
-    }
-    if (db) {
-        float a = 0.f;
-        for (int m = threadIdx.x; m < rows; m += 256) a += dy[m];
-        red[threadIdx.x] = a;
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-            if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-            __syncthreads();
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    float a = 0.f, bs = 0.f;
+    if (c < D) {
+        const float wc = w[c];
+        for (int m = rl; m < rows; m += 4) {
+            const float g = dy[m];
+            dx[(size_t)m * D + c] = g * wc;
+            a += g * x[(size_t)m * ldx + c];
         }
-        if (threadIdx.x == 0) db[0] = red[0];
+    }
+    if (blockIdx.x == 0 && cl == 0)
+        for (int m = rl; m < rows; m += 4) bs += dy[m];
+    red[rl][cl] = a;
+    __syncthreads();
+    if (rl == 0 && c < D) dw[c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    __syncthreads();
+    if (db && blockIdx.x == 0) {
+        if (cl == 0) red[rl][0] = bs;
+        __syncthreads();
+        if (threadIdx.x == 0) db[0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
     }
 }
 
@@ -338,7 +340,7 @@ extern "C" int medp_rowdot_fwd(const float* x, int ldx, const float* w, const fl
 extern "C" int medp_rowdot_bwd(const float* dy, const float* x, int ldx, const float* w, float* dx, float* dw, float* db, int rows,
                                int D, void* stream) {
     MEDP_CHECK_ARG(dy && x && w && dx && dw && rows > 0 && D > 0, "rowdot_bwd: bad argument");
-    rowdot_bwd_kernel<<<1, 256, 0, (hipStream_t)stream>>>(dy, x, ldx, w, dx, dw, db, rows, D);
+    rowdot_bwd_kernel<<<(D + 63) / 64, 256, 0, (hipStream_t)stream>>>(dy, x, ldx, w, dx, dw, db, rows, D);
     MEDP_LAUNCH_CHECK("medp_rowdot_bwd");
     return 0;
 }

@@ -319,7 +319,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_v3_kernel(const GemmParam
     const int bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+    // L2-aware linearisation: an XCD's contiguous run of ~nwg/8 ids walks one BAND of 8 row-tiles in SUPER-COLUMNS of 8
+    // column-tiles, so the 64 tiles it runs concurrently (2 per CU x 32 CUs) share 8 A panels and 8 W panels (~4.7 MB at
+    // K = 768) instead of 3 A panels and ALL of W (PMC: 2.4x the algorithmic fetch with the row-major order).
+    constexpr int MB = 8, SN = 8;
+    const int band = wg / (MB * tiles_n), rb = wg % (MB * tiles_n);
+    const int mb = min(MB, tiles_m - band * MB);
+    const int sc = rb / (mb * SN), r2 = rb % (mb * SN);
+    const int sn = min(SN, tiles_n - sc * SN);
+    const int m0 = (band * MB + r2 / sn) * BM, n0 = (sc * SN + r2 % sn) * BN;
     const int nkt = (p.K + 31) >> 5;
     const bf16_t* zero = (const bf16_t*)g_zero16;
 

@@ -272,7 +272,7 @@ class Model(nn.Module):
         tm = self.full_time_embedding
         ms, mb = tm[2].folded()
         w.time_w0, w.time_b0, w.time_bn_scale, w.time_bn_shift = f32(tm[0].weight[:, 0]), f32(tm[0].bias), f32(ms), f32(mb)
-        w.time_w3, w.time_b3 = f32(tm[3].weight), f32(tm[3].bias)
+        w.time_w3t, w.time_b3 = f32(tm[3].weight.t()), f32(tm[3].bias)
         w.rep_embedding = f32(self.full_rep_embedding.weight[:, 0])
         w.event_embedding = f32(self.full_event_embedding.weight)
 
