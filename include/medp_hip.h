@@ -195,6 +195,10 @@ int medp_aux_residual_kl(const float* img_logits, const float* scaled_correction
 int medp_sq_mean(const float* x, float coef, float* out, float* g, int n, void* stream);
 int medp_masked_bce_global(const float* logits, const float* y, const float* mask, float* out, float* g, int n, void* stream);
 
+/* DuETT-only step losses (duett/duett.py:337-365): mean(((a-b)*mask)^2) and mean(weight * BCEWithLogits); mask/weight may be NULL */
+int medp_masked_mse(const float* a, const float* b, const float* mask, float* out, float* g_a, int n, void* stream);
+int medp_bce_mean(const float* logits, const float* y, const float* weight, float* out, float* g, int n, void* stream);
+
 /* ---- optimiser: torch.optim.AdamW semantics over a device table of tensors (trainer.py:77-116,383) -------------- */
 typedef struct {
     void* param;            /* fp32, updated in place */

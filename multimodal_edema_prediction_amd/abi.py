@@ -104,6 +104,8 @@ SIGNATURES = {
     "medp_psi_assemble_bwd": (I, [P, P, P, P, P, I, I, I, I, P]),
     "medp_axis_swap": (I, [P, P, I, I, I, I, P]),
     "medp_add_bcast": (I, [P, P, P, LL, I, I, P]),
+    "medp_masked_mse": (I, [P, P, P, P, P, I, P]),
+    "medp_bce_mean": (I, [P, P, P, P, P, I, P]),
     "medp_adamw_chunk_elems": (I, []),
     "medp_adamw_multi": (I, [P, P, P, I, F, F, F, I, P, F, P]),
     "medp_rng_set_epoch_ptr": (I, [P]),

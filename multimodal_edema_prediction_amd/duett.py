@@ -322,6 +322,20 @@ class Model(nn.Module):
         return tok, tok16, psi0
 
 
+def _attach_ssl_methods():
+    """`Model.pretrain_prep_batch`, `Model.forward`, `Model.training_step` (duett.py:189-372) live in duett_ssl.py."""
+    from . import duett_ssl
+
+    Model.pretrain_prep_batch = lambda self, x, batch_size: duett_ssl.pretrain_prep_batch(self, x, batch_size)
+    Model.forward = lambda self, x, pretrain=False, representation=False: duett_ssl.model_forward(self, x, pretrain, representation)
+    Model.training_step = lambda self, batch, batch_idx=0: duett_ssl.training_step_loss(self, batch)
+
+
+def pretrain_model(d_static_num, d_time_series_num, d_target, **kwargs):
+    """duett.py:41-42."""
+    return Model(d_static_num, d_time_series_num, d_target, **kwargs)
+
+
 class DuettFeatureExtractor(Model):
     """Mirror of model file :24-94."""
 
@@ -366,3 +380,6 @@ def load_duett_backbone(ckpt_path: str, d_static_num: int, d_time_series_num: in
             p.requires_grad = False
         model.eval()
     return model
+
+
+_attach_ssl_methods()

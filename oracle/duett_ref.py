@@ -166,3 +166,67 @@ def student_forward(sd, cfg: DuettCfg, duett_in, pool="mean", training=False):
     feat = tok[:, -1, :] if pool == "rep_token" else tok[:, :-1, :].mean(dim=1)
     h = F.gelu(F.linear(feat, sd["head.0.weight"], sd["head.0.bias"]))
     return F.linear(h, sd["head.3.weight"], sd["head.3.bias"]).squeeze(-1)
+
+
+# --------------------------------------------------------------------------- a17 (config 1: DuETT-only SSL / supervised step)
+def pretrain_prep_batch(x, rng, n_vars, max_len, pretrain_dropout=0.5, predict_events=True):
+    """`Model.pretrain_prep_batch` (duett.py:189-237) for pretrain_masked_steps == 1: one masked timestep and one masked
+    event per sample, drawn from the model's numpy Generator in the reference's call order, then variable dropout."""
+    xs_static, xs_ts, xs_times, n_timesteps = feats_to_input(x, max_len)
+    B = xs_ts.shape[0]
+    y_ts, y_ts_n_obs, y_events, y_events_mask = [], [], [], []
+    clipped = xs_ts.clone()
+    for b, n in enumerate(n_timesteps):
+        mask_i = n if n < 2 else rng.choice(np.arange(0, n))                    # :199-207
+        y_ts.append(xs_ts[b, mask_i, :n_vars])
+        y_ts_n_obs.append(xs_ts[b, mask_i, n_vars:2 * n_vars])
+        clipped[b, mask_i, :] = 0.0
+        clipped[b, mask_i, -1] = 1.0
+        if predict_events:                                                       # :214-219
+            ev = rng.choice(np.arange(0, n_vars))
+            y_events.append(xs_ts[b, :, ev])
+            y_events_mask.append(xs_ts[b, :, ev + n_vars].clip(0, 1))
+            clipped[b, :, ev] = 0
+            clipped[b, :, ev + n_vars] = -1
+    y_ts, y_ts_masks = torch.stack(y_ts), torch.stack(y_ts_n_obs).clip(0, 1)
+    if predict_events:
+        y_events, y_events_mask = torch.stack(y_events), torch.stack(y_events_mask)
+    if pretrain_dropout > 0:                                                     # :227-236
+        keep = torch.tensor(rng.random((B, n_vars)) > pretrain_dropout)
+        keep = torch.logical_or(1 - y_ts_masks, keep)
+        keep = torch.cat((keep.tile(1, 2), torch.ones((B, 1))), dim=1)
+        clipped = clipped * torch.logical_or(keep.unsqueeze(1), clipped == -1)
+    return (xs_static, clipped, xs_times, n_timesteps), y_ts, y_ts_masks, y_events, y_events_mask
+
+
+def model_forward(sd, cfg: DuettCfg, x, pretrain=False, fusion_method="masked_embed", training=False):
+    """`Model.forward` (duett.py:239-323), pretrain_masked_steps == 1."""
+    xs_static, xs_feats, xs_times, _ = x
+    tok, inter = encode(sd, cfg, x, training, return_intermediates=True)
+    psi = inter[f"psi{cfg.n_layers}"]
+    B = tok.shape[0]
+    if fusion_method == "rep_token":
+        z = tok[:, -1, :]
+    elif fusion_method == "masked_embed":
+        idx = (xs_feats[:, :, -1] == 1).float().argmax(dim=1)
+        z = tok[torch.arange(B), idx]
+    else:
+        z = tok[:, :-1, :].mean(dim=1)
+    if pretrain:
+        lin = lambda name, v: F.linear(v, sd[name + ".0.weight"], sd[name + ".0.bias"])
+        V = cfg.d_time_series_num
+        ev_idx = (xs_feats[:, 0, V:2 * V] == -1).float().argmax(dim=1)
+        z_events = psi[torch.arange(B), :, ev_idx, :].flatten(1)                 # :311-313
+        return (lin("pretrain_value_proj", z), lin("pretrain_presence_proj", z), lin("predict_events_proj", z_events),
+                lin("predict_events_presence_proj", z_events))
+    h = F.relu(F.linear(z, sd["head.0.weight"], sd["head.0.bias"]))
+    h = batchnorm_lastdim(h, sd, "head.3.", training)
+    return F.linear(h, sd["head.4.weight"], sd["head.4.bias"]).squeeze(1)
+
+
+def ssl_loss(y_hat_value, y_hat_presence, y_hat_events, y_hat_events_presence, y, mask, y_events, y_events_mask, presence_weight=0.2):
+    """`Model.training_step`, pretrain branch (duett.py:337-358)."""
+    loss = F.mse_loss(y_hat_value * mask, y * mask)
+    loss = loss + F.binary_cross_entropy_with_logits(y_hat_presence, mask) * presence_weight
+    loss = loss + F.mse_loss(y_hat_events * y_events_mask, y_events * y_events_mask)
+    return loss + F.binary_cross_entropy_with_logits(y_hat_events_presence, y_events_mask) * presence_weight
