@@ -39,6 +39,11 @@ int medp_gemm_bf16_nt(const void* A, const void* W, void* C, int M, int N, int K
                       const float* bias, const float* scale, const float* residual, int ldr, int act, int out_bf16,
                       void* stream);
 
+/* Weight gradient C[N,K] = sum_m dY[m,n] X[m,k] (fp32 out, bf16 row-major operands, transposing LDS reads, split over m with
+ * a deterministic slab reduction): the dW of every trainable Linear (autograd of model :566,:749-757,:1027, duett.py:95-105). */
+size_t medp_gemm_tn_workspace_bytes(int M, int N, int K);
+int medp_gemm_bf16_tn(const void* dY, const void* X, float* C, int M, int N, int K, int lddy, int ldx, float* workspace, void* stream);
+
 /* Live timing of the step's dominant kernel (the CXR-encoder block GEMMs launched by medp_vit_forward): when enabled,
  * HIP events bracket every such launch on its own stream; collect() synchronises the events (host side) and returns the
  * summed kernel time, the launch count and the algorithmic FLOPs (2*M*N*K per launch).  Used by bench.py's roofline leg. */

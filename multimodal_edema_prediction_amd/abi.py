@@ -55,6 +55,8 @@ SIGNATURES = {
     "medp_version": (I, []),
     "medp_arch": (c_char_p, []),
     "medp_gemm_bf16_nt": (I, [P, P, P, I, I, I, I, I, I, P, P, P, I, I, I, P]),
+    "medp_gemm_tn_workspace_bytes": (SZ, [I, I, I]),
+    "medp_gemm_bf16_tn": (I, [P, P, P, I, I, I, I, I, P, P]),
     "medp_gemm_profile_enable": (I, [I]),
     "medp_gemm_profile_collect": (I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_longlong), ctypes.POINTER(ctypes.c_double)]),
     "medp_attn_fwd_dh64": (I, [P, P, P, P, I, I, I, I, I, I, I, F, P]),

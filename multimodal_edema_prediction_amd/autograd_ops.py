@@ -101,14 +101,18 @@ class LinearFn(torch.autograd.Function):
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = Fn.colsum(dy2)
             return dx, dw, db, None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] or (ctx.needs_input_grad[1] and N % 8 == 0 and K % 8 == 0):
             dyb = Fn.to_bf16(dy2) if N % 4 == 0 else dy2.to(BF16)
+        if ctx.needs_input_grad[0]:
             wt = weight_t_bf16(weight)                           # [K, Npad]
             dx = Fn.gemm(dyb, wt, out_dtype=F32, k=N).view(ctx.x_shape)
         if ctx.needs_input_grad[1]:
-            dyt = Fn.transpose_to_bf16(dy2)                      # [N, Mpad]
-            xt = Fn.transpose_to_bf16(x2)                        # [K, Mpad]
-            dw = Fn.gemm(dyt, xt, out_dtype=F32, k=dyt.shape[1])  # [N, K]
+            if N % 8 == 0 and K % 8 == 0 and x2.stride(0) % 8 == 0:
+                dw = Fn.gemm_tn(dyb, x2)                         # transposing LDS reads + split-m: no dY^T / X^T passes
+            else:
+                dyt = Fn.transpose_to_bf16(dy2)                  # [N, Mpad]
+                xt = Fn.transpose_to_bf16(x2)                    # [K, Mpad]
+                dw = Fn.gemm(dyt, xt, out_dtype=F32, k=dyt.shape[1])  # [N, K]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = Fn.colsum(dy2)
         dres = dy if (ctx.has_res and ctx.needs_input_grad[3]) else None

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "common.h"
+#include "gemm_v4.h"
 #include "medp_hip.h"
 
 namespace {
@@ -533,8 +534,11 @@ int medp_gemm_bf16_nt_tagged(int tag, const void* A, const void* W, void* C, int
     hipStream_t s = (hipStream_t)stream;
     static const int force = [] { const char* e = getenv("MEDP_GEMM_VARIANT"); return e ? atoi(e) : 0; }();   // 1 = v1, 2 = v2 (A/B tests)
     const bool use_v2 = force == 2;
+    const bool use_v4 = force == 4;                                  // persistent variant (gemm_bf16_v4.hip)
     const bool use_v3 = force == 3 || (force == 0 && M >= 2048 && N >= 256);
+    const MedpGemmArgs a4{A, W, C, M, N, K, lda, ldw, ldc, bias, scale, residual, ldr, act, out_bf16};
     if (N <= 64) return launch<128, 64, 0>(p, s);
+    if (use_v4 && tag != 1 && M >= 2048 && N >= 256) return medp_gemm_v4_launch(a4, 0, stream);
     if (use_v3 && tag != 1) return launch_v3<0>(p, s);
     if (use_v2 && tag != 1) return launch_v2<0>(p, s);
     if (tag == 1) {
@@ -549,7 +553,8 @@ int medp_gemm_bf16_nt_tagged(int tag, const void* A, const void* W, void* C, int
             }
             hipEventRecord(g_prof.ev[g_prof.used], s);
         }
-        const int rc = use_v3 ? launch_v3<1>(p, s) : (use_v2 ? launch_v2<1>(p, s) : launch<128, 128, 1>(p, s));
+        const int rc = use_v4 ? medp_gemm_v4_launch(a4, 1, stream)
+                              : (use_v3 ? launch_v3<1>(p, s) : (use_v2 ? launch_v2<1>(p, s) : launch<128, 128, 1>(p, s)));
         if (prof) {
             hipEventRecord(g_prof.ev[g_prof.used + 1], s);
             g_prof.used += 2;

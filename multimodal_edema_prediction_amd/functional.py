@@ -53,6 +53,20 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, scale=None, residual=None,
     return out
 
 
+def gemm_tn(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """dW[N,K] = dy[M,N]^T @ x[M,K] (bf16 row-major operands, fp32 result) — the weight gradient of a Linear."""
+    assert dy.dtype == BF16 and x.dtype == BF16
+    dy2, x2 = _2d(dy), _2d(x)
+    M, N = dy2.shape
+    K = x2.shape[1]
+    assert x2.shape[0] == M
+    out = torch.empty((N, K), dtype=F32, device=dy.device)
+    wsb = lib().medp_gemm_tn_workspace_bytes(M, N, K)
+    ws = torch.empty(wsb // 4, dtype=F32, device=dy.device) if wsb else None
+    check(lib().medp_gemm_bf16_tn(ptr(dy2), ptr(x2), ptr(out), M, N, K, _ld(dy2), _ld(x2), ptr(ws), stream()), "gemm_tn")
+    return out
+
+
 def layernorm(x: torch.Tensor, w, b, eps: float, out_dtype=BF16, save_stats: bool = False):
     x2 = _2d(x)
     rows, D = x2.shape

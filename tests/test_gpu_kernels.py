@@ -218,3 +218,20 @@ def test_gelu_bwd():
     pr = pre.clone().double().requires_grad_(True)
     torch.nn.functional.gelu(pr).backward(dy.double())
     assert_close(Fn.gelu_bwd(dy.to(DEV), pre.to(DEV)), pr.grad, 1e-5, 1e-6, "gelu bwd")
+
+
+@pytest.mark.parametrize("M,N,K", [(16448 // 4, 256, 768), (448, 1024, 256), (6144 // 2, 512, 256), (100, 64, 256), (3136, 72, 2328 // 3 // 8 * 8),
+                                   (64, 128, 408), (2056, 256, 1176)])
+def test_gemm_tn_weight_gradient(M, N, K):
+    """dW = dY^T X with transposing LDS reads and split-m slabs, vs fp64 on bf16-representable operands."""
+    dy = bf_round(rnd(M, N, seed=1))
+    x = bf_round(rnd(M, K, seed=2))
+    want = dy.double().T @ x.double()
+    got = Fn.gemm_tn(dy.to(DEV).bfloat16(), x.to(DEV).bfloat16())
+    assert got.shape == (N, K)
+    assert_close(got, want, 1e-4, 2e-4 * math.sqrt(M), f"gemm_tn {M}x{N}x{K}")
+    # asymmetric identity check: dY = one-hot rows picks rows of X
+    dy1 = torch.zeros(M, N)
+    dy1[torch.arange(min(M, N)), torch.arange(min(M, N))] = 1.0
+    got1 = Fn.gemm_tn(dy1.to(DEV).bfloat16(), x.to(DEV).bfloat16())
+    assert torch.equal(got1[:min(M, N)].cpu(), x[:min(M, N)])
