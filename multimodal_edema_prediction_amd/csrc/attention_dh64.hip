@@ -1,7 +1,9 @@
 // Flash-style attention forward for head dim 64 on gfx950 (the ViT-B/14 CXR encoder: 12 heads, 257 / 1297 tokens).
 //   O[b,s,h,:] = softmax(Q K^T * scale) V,  dense, no mask, bf16 in / bf16 out, fp32 softmax.
 //
-// One 256-thread workgroup = 4 waves handles 128 queries of one (batch, head); each wave owns 32 queries.
+// One 256-thread workgroup = 4 waves of one (batch, head).  The ceil(S/16) 16-query subtiles are dealt evenly over the
+// 4*gridDim.x waves (1..3 subtiles per wave, one pass each): for S = 257 that is two workgroups per (b, h) with one wave
+// carrying the odd CLS subtile, instead of a third workgroup that stages all of K/V for a single query.
 // K and V for a chunk of up to 320 keys sit in LDS (row-major [key][64], 128-B rows, XOR-swizzled 16-B
 // chunks, filled by LDS-DMA) and are shared by the 4 waves.  Per 64-key block a wave computes
 //   S^T = K Q^T   (MFMA 16x16x32, A := K rows, B := Q rows -> key on the accumulator rows, query on the lane)
@@ -17,6 +19,7 @@ namespace {
 __device__ __attribute__((aligned(16))) uint32_t g_zero16_attn[4] = {0, 0, 0, 0};
 
 constexpr int KC = 320;   // keys per LDS chunk (5 blocks of 64)
+constexpr int NQ = 3;     // most 16-query subtiles one wave carries
 
 struct AttnParams {
     const bf16_t *q, *k, *v;
@@ -44,26 +47,29 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dh64_kernel(const AttnParams 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, kq = lane >> 4;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int ntile = (p.S + 15) >> 4, nwave = gridDim.x * 4, gw = blockIdx.x * 4 + wave;
+    const int tbase = ntile / nwave, trem = ntile % nwave;
+    const int nq = tbase + (gw < trem ? 1 : 0);                 // subtiles of this wave (wave-uniform, <= NQ)
+    const int q0 = (gw * tbase + min(gw, trem)) * 16;
     const bf16_t* zero = (const bf16_t*)g_zero16_attn;
     const size_t row0 = (size_t)b * p.S;
 
     // ---- Q fragments (B operand: lane = query, 8 consecutive d) --------------------------------
-    bf16x8 qf[2][2];
+    bf16x8 qf[NQ][2];
 #pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
+    for (int qs = 0; qs < NQ; ++qs) {
         const int qi = q0 + qs * 16 + fr;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const bf16_t* src = (qi < p.S) ? p.q + (row0 + qi) * p.ldq + h * 64 + s * 32 + kq * 8 : zero;
+            const bf16_t* src = (qs < nq && qi < p.S) ? p.q + (row0 + qi) * p.ldq + h * 64 + s * 32 + kq * 8 : zero;
             qf[qs][s] = *(const bf16x8*)src;
         }
     }
 
-    f32x4 o[2][4];
-    float m_run[2], l_run[2];
+    f32x4 o[NQ][4];
+    float m_run[NQ], l_run[NQ];
 #pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
+    for (int qs = 0; qs < NQ; ++qs) {
         m_run[qs] = -INFINITY;
         l_run[qs] = 0.f;
 #pragma unroll
@@ -88,18 +94,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dh64_kernel(const AttnParams 
         }
         __syncthreads();
 
-        const int nblk = (nkeys + 63) >> 6;
+        const int nblk = (nq > 0) ? (nkeys + 63) >> 6 : 0;
         for (int kb = 0; kb < nblk; ++kb) {
-            // ---- S^T = K Q^T for 64 keys x 32 queries ------------------------------------------
-            f32x4 st[2][4];
+            // 16-key tiles of this block that hold at least one real key (wave-uniform; < 4 only on the ragged tail)
+            const int ktv = min(4, (nkeys - kb * 64 + 15) >> 4);
+            // ---- S^T = K Q^T for 64 keys x 16*nq queries ----------------------------------------
+            f32x4 st[NQ][4];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
+                if (kt >= ktv) {
+#pragma unroll
+                    for (int qs = 0; qs < NQ; ++qs) st[qs][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    continue;
+                }
                 const int krow = kb * 64 + kt * 16 + fr;
                 const char* base = sK + krow * 128;
                 const bf16x8 k0 = *(const bf16x8*)(base + (((0 + kq) ^ (krow & 7)) << 4));
                 const bf16x8 k1 = *(const bf16x8*)(base + (((4 + kq) ^ (krow & 7)) << 4));
 #pragma unroll
-                for (int qs = 0; qs < 2; ++qs) {
+                for (int qs = 0; qs < NQ; ++qs) {
+                    if (qs >= nq) continue;
                     f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
                     a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[qs][0], a, 0, 0, 0);
                     a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qs][1], a, 0, 0, 0);
@@ -109,12 +123,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dh64_kernel(const AttnParams 
             // ---- scale, mask the ragged tail, online softmax ------------------------------------
             const bool tail = (kb * 64 + 64 > nkeys);
 #pragma unroll
-            for (int qs = 0; qs < 2; ++qs) {
+            for (int qs = 0; qs < NQ; ++qs) {
+                if (qs >= nq) continue;
                 float mx = -INFINITY;
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
+                        if (kt >= ktv) continue;
                         float s = st[qs][kt][r] * p.scale_log2e;
                         if (tail && (kb * 64 + kt * 16 + kq * 4 + r >= nkeys)) s = -INFINITY;
                         st[qs][kt][r] = s;
@@ -130,6 +146,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dh64_kernel(const AttnParams 
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
+                        if (kt >= ktv) continue;     // st stays 0: no weight on absent keys
                         const float e = exp2f(st[qs][kt][r] - m_new);
                         st[qs][kt][r] = e;
                         ls += e;
@@ -141,9 +158,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dh64_kernel(const AttnParams 
             // ---- O^T += V^T P^T ---------------------------------------------------------------------
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 pf[2];
+                if (2 * ks >= ktv) continue;
+                bf16x8 pf[NQ];
 #pragma unroll
-                for (int qs = 0; qs < 2; ++qs) {
+                for (int qs = 0; qs < NQ; ++qs) {
                     const f32x4 a = st[qs][2 * ks], c = st[qs][2 * ks + 1];
                     union { bf16x8 v; uint32_t u[4]; } pk;
                     pk.u[0] = pack_bf2(a[0], a[1]);
@@ -164,8 +182,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dh64_kernel(const AttnParams 
                     vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
                     vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
 #pragma unroll
-                    for (int qs = 0; qs < 2; ++qs)
-                        o[qs][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qs], o[qs][dt], 0, 0, 0);
+                    for (int qs = 0; qs < NQ; ++qs)
+                        if (qs < nq) o[qs][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qs], o[qs][dt], 0, 0, 0);
                 }
             }
         }
@@ -173,7 +191,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dh64_kernel(const AttnParams 
 
     // ---- normalise and store: lane holds O[q = fr][d = dt*16 + kq*4 .. +3] --------------------------
 #pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
+    for (int qs = 0; qs < NQ; ++qs) {
+        if (qs >= nq) continue;
         float l = l_run[qs];
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
@@ -207,7 +226,9 @@ extern "C" int medp_attn_fwd_dh64(const void* q, const void* k, const void* v, v
         hipFuncSetAttribute((const void*)attn_fwd_dh64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    dim3 grid((S + 127) / 128, H, B);
+    // floor(ntile/8) workgroups: every wave gets 1..3 subtiles (ntile < 8*(nb+1) <= 12*nb)
+    const int ntile = (S + 15) / 16;
+    dim3 grid(ntile >= 8 ? ntile / 8 : 1, H, B);
     attn_fwd_dh64_kernel<<<grid, 256, LDS, (hipStream_t)stream>>>(p);
     MEDP_LAUNCH_CHECK("medp_attn_fwd_dh64");
     return 0;

@@ -538,6 +538,13 @@ int medp_gemm_bf16_nt_tagged(int tag, const void* A, const void* W, void* C, int
     const bool use_v3 = force == 3 || (force == 0 && M >= 2048 && N >= 256);
     const MedpGemmArgs a4{A, W, C, M, N, K, lda, ldw, ldc, bias, scale, residual, ldr, act, out_bf16};
     if (N <= 64) return launch<128, 64, 0>(p, s);
+    const bool use_v5 = force == 5 && M >= 2048 && N >= 256;         // 256 x 256 tiles, 128 x 128 per wave (gemm_bf16_v5.hip)
+    // v6 (256 x 256 x 64, 8 waves ping-pong, gemm_bf16_v6.hip) runs ONE workgroup per CU: default once there are enough
+    // 256^2 tiles to occupy most of the chip (the CXR-encoder shapes: 195 / 585 / 780 tiles); v3 keeps the smaller grids
+    const int tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
+    const bool use_v6 = M >= 2048 && N >= 256 && (force == 6 || (force == 0 && tiles256 >= 160));
+    if (use_v6 && tag != 1) return medp_gemm_v6_launch(a4, 0, stream);
+    if (use_v5 && tag != 1) return medp_gemm_v5_launch(a4, 0, stream);
     if (use_v4 && tag != 1 && M >= 2048 && N >= 256) return medp_gemm_v4_launch(a4, 0, stream);
     if (use_v3 && tag != 1) return launch_v3<0>(p, s);
     if (use_v2 && tag != 1) return launch_v2<0>(p, s);
@@ -553,7 +560,7 @@ int medp_gemm_bf16_nt_tagged(int tag, const void* A, const void* W, void* C, int
             }
             hipEventRecord(g_prof.ev[g_prof.used], s);
         }
-        const int rc = use_v4 ? medp_gemm_v4_launch(a4, 1, stream)
+        const int rc = use_v6 ? medp_gemm_v6_launch(a4, 1, stream) : use_v5 ? medp_gemm_v5_launch(a4, 1, stream) : use_v4 ? medp_gemm_v4_launch(a4, 1, stream)
                               : (use_v3 ? launch_v3<1>(p, s) : (use_v2 ? launch_v2<1>(p, s) : launch<128, 128, 1>(p, s)));
         if (prof) {
             hipEventRecord(g_prof.ev[g_prof.used + 1], s);

@@ -1,0 +1,248 @@
+// v6: 256 x 256 x 64 tiles, EIGHT waves (2 x 4, 128 x 64 per wave), two waves per SIMD in PING-PONG.
+//
+// v3/v5 measurements: a wave that owns its SIMD alone pays for every LDS-DMA issue (~100+ cycles inside a K-step that also
+// carries the fragment reads) and for every barrier with an idle matrix pipe.  Here each SIMD holds one wave of group 0
+// (rows 0..127 of the tile) and one of group 1 (rows 128..255).  A K-tile (64 deep) is four PHASES of 16 MFMAs (one
+// 64 x 32 quadrant of the wave's 128 x 64 output, both k-halves); every phase is
+//     [load section: ds_read fragments, 2 LDS-DMA pieces, lgkmcnt(0)]  s_barrier  [16 MFMA at raised priority]  s_barrier
+// and group 1 runs ONE barrier behind group 0, so between any two consecutive barriers one group multiplies while the
+// other issues its loads: the matrix pipe always has a wave whose operands are already in registers.
+//
+// LDS: two K-tile buffers of 64 KiB = four 16-KiB half-tiles each (A rows 0-127 | A rows 128-255 | W rows 0-127 |
+// W rows 128-255), 128-B rows, 16-B chunk c stored at c ^ (row & 7) (conflict-free ds_read_b128 lane groups).
+// Fragment schedule of K-tile t (per wave): P1 reads A0 (8) + W0 (4), P2 W1 (4), P3 A1 (8), P4 nothing;
+// MFMA quadrants: P1 (A0,W0)  P2 (A0,W1)  P3 (A1,W1)  P4 (A1,W0).
+// LDS-DMA stream, one half-tile (2 pieces per lane) per phase, each into a region whose last read ended >= 1 phase ago:
+//     P1(t): A-lo(t+1)   P2(t): A-hi(t+1)   P3(t): W-lo(t+2)   P4(t): W-hi(t+2), then vmcnt(4) -> K-tile t+1 landed.
+// RAW: the retiring wait sits in P4(t)'s load section (before a barrier every wave passes); K-tile t+1 is first read in
+// P1(t+1), one phase later.  WAR: every ds_read is retired (lgkmcnt(0)) before the barrier that ends its load section.
+#include <stdlib.h>
+
+#include "common.h"
+#include "gemm_v4.h"
+
+namespace {
+
+__device__ __attribute__((aligned(16))) uint32_t g_zero16_v6[4] = {0, 0, 0, 0};
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+constexpr int BM = 256, BN = 256, HALF = 128 * 128, KBUF = 4 * HALF;   // 16 KiB half-tile, 64 KiB K-tile buffer
+constexpr int LDS_MAIN = 2 * KBUF, LDS_EPI = 8 * 64 * 68 * 4, LDS_BYTES = LDS_EPI > LDS_MAIN ? LDS_EPI : LDS_MAIN;
+
+#define MEDP_BAR()                                  \
+    do {                                            \
+        __builtin_amdgcn_sched_barrier(0);          \
+        __builtin_amdgcn_s_barrier();               \
+        __builtin_amdgcn_sched_barrier(0);          \
+    } while (0)
+
+template <int TAG>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v6_kernel(const MedpGemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, kq = lane >> 4;
+    const int wm = wave >> 2, wn = wave & 3;          // wm = ping-pong group
+    const bf16_t* A = (const bf16_t*)p.A;
+    const bf16_t* W = (const bf16_t*)p.W;
+    const bf16_t* zero = (const bf16_t*)g_zero16_v6;
+
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    constexpr int MB = 8, SN = 4;                      // band / super-column order, see v3
+    const int band = wg / (MB * tiles_n), rb = wg % (MB * tiles_n);
+    const int mb = min(MB, tiles_m - band * MB);
+    const int sc = rb / (mb * SN), r2 = rb % (mb * SN);
+    const int sn = min(SN, tiles_n - sc * SN);
+    const int m0 = (band * MB + r2 / sn) * BM, n0 = (sc * SN + r2 % sn) * BN;
+    const int nkt = (p.K + 63) >> 6;
+
+    // ---- LDS-DMA staging: half-tile = 128 rows x 8 chunks; lane's two pieces are rows (tid>>3) and (tid>>3)+64 ------
+    const int srow = tid >> 3, schunk = (tid & 7) ^ (srow & 7);       // source chunk for LDS position (tid & 7)
+    const bf16_t* a_src[2][2];                                        // [half][piece] row base (k = 0) or nullptr
+    const bf16_t* w_src[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ra = m0 + h * 128 + j * 64 + srow, rw = n0 + h * 128 + j * 64 + srow;
+            a_src[h][j] = ra < p.M ? A + (size_t)ra * p.lda + schunk * 8 : nullptr;
+            w_src[h][j] = rw < p.N ? W + (size_t)rw * p.ldw + schunk * 8 : nullptr;
+        }
+    // which = 0: A-lo, 1: A-hi, 2: W-lo, 3: W-hi of K-tile kt -> buffer kt & 1
+    auto stage_half = [&](int kt, int which) {
+        char* dst = smem + (kt & 1) * KBUF + which * HALF + wave * 1024;
+        const int k0 = kt * 64;
+        const bool kin = k0 + schunk * 8 < p.K;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bf16_t* base = which < 2 ? a_src[which & 1][j] : w_src[which & 1][j];
+            const bf16_t* src = (base != nullptr && kin) ? base + k0 : zero;
+            glds16(src, dst + j * 8192);
+        }
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // prologue: K-tile 0 complete + the W halves of K-tile 1 (what the steady-state stream would have issued by now)
+    stage_half(0, 2);
+    stage_half(0, 3);
+    stage_half(0, 0);
+    stage_half(0, 1);
+    stage_half(1, 2);
+    stage_half(1, 3);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+
+    // fragment read addresses: row = base + 16*i + fr, chunk (kh*4 + kq) ^ (row & 7); row & 7 == fr & 7 (bases are multiples of 16)
+    const int sw = fr & 7;
+    const int fa_off = wm * HALF + fr * 128;                          // + a*64 rows*128 + i*16*128 ; chunk term added per kh
+    const int fw_off = 2 * HALF + (wn >> 1) * HALF + ((wn & 1) * 64 + fr) * 128;
+    const int ch0 = ((0 + kq) ^ sw) << 4, ch1 = ((4 + kq) ^ sw) << 4;
+
+    bf16x8 fa[4][2], fw0[2][2], fw1[2][2];
+    auto read_a = [&](const char* buf, int a) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const char* rp = buf + fa_off + (a * 64 + i * 16) * 128;
+            fa[i][0] = *(const bf16x8*)(rp + ch0);
+            fa[i][1] = *(const bf16x8*)(rp + ch1);
+        }
+    };
+    auto read_w = [&](const char* buf, int b, bf16x8 (*fw)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const char* rp = buf + fw_off + (b * 32 + j * 16) * 128;
+            fw[j][0] = *(const bf16x8*)(rp + ch0);
+            fw[j][1] = *(const bf16x8*)(rp + ch1);
+        }
+    };
+    // ragged last row-tile (M = 64 * 257 leaves 64 valid rows of 256): a 64-row quadrant entirely past M keeps its zero
+    // accumulators and skips its MFMAs (wave-uniform), so that tile costs its loads and barriers only
+    const bool rows_live[2] = {m0 + wm * 128 < p.M, m0 + wm * 128 + 64 < p.M};
+    auto mma = [&](int a, int b, const bf16x8 (*fw)[2]) {
+        if (!rows_live[a]) return;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[a * 4 + i][b * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j][kh], fa[i][kh], acc[a * 4 + i][b * 2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    MEDP_BAR();                    // K-tile 0 visible to everyone
+    if (wm == 1) MEDP_BAR();       // group 1 runs one barrier behind (group 0 pays its extra barrier after the loop)
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const char* buf = smem + (kt & 1) * KBUF;
+        // ---- P1
+        read_w(buf, 0, fw0);
+        read_a(buf, 0);
+        stage_half(kt + 1, 0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0), vmcnt/expcnt untouched
+        MEDP_BAR();
+        mma(0, 0, fw0);
+        MEDP_BAR();
+        // ---- P2
+        read_w(buf, 1, fw1);
+        stage_half(kt + 1, 1);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        MEDP_BAR();
+        mma(0, 1, fw1);
+        MEDP_BAR();
+        // ---- P3
+        read_a(buf, 1);
+        stage_half(kt + 2, 2);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        MEDP_BAR();
+        mma(1, 1, fw1);
+        MEDP_BAR();
+        // ---- P4
+        stage_half(kt + 2, 3);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but W-lo/W-hi(kt+2): K-tile kt+1 has landed
+        MEDP_BAR();
+        mma(1, 0, fw0);
+        MEDP_BAR();
+    }
+    if (wm == 0) MEDP_BAR();
+
+    // ---- epilogue through LDS (whole-row coalesced global accesses), as v3 ------------------------------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* wl = (float*)(smem + wave * (64 * 68 * 4));
+    const int er = lane >> 4, ec = (lane & 15) * 4;
+    const int n = n0 + wn * 64 + ec;
+    f32x4 bias4 = (f32x4){0.f, 0.f, 0.f, 0.f}, scale4 = (f32x4){1.f, 1.f, 1.f, 1.f};
+    if (n < p.N) {
+        if (p.bias) bias4 = *(const f32x4*)(p.bias + n);
+        if (p.scale) scale4 = *(const f32x4*)(p.scale + n);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(f32x4*)(wl + (i4 * 16 + fr) * 68 + j * 16 + kq * 4) = acc[half * 4 + i4][j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int rr = it * 4 + er;
+            const int m = m0 + wm * 128 + half * 64 + rr;
+            f32x4 v = *(const f32x4*)(wl + rr * 68 + ec);
+            if (m < p.M && n < p.N) {
+                v += bias4;
+                if (p.act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                }
+                v *= scale4;
+                if (p.residual) v += *(const f32x4*)(p.residual + (size_t)m * p.ldr + n);
+                if (p.out_bf16) {
+                    uint2 o;
+                    o.x = pack_bf2(v[0], v[1]);
+                    o.y = pack_bf2(v[2], v[3]);
+                    *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+                } else {
+                    *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
+template <int TAG>
+int launch_v6(const MedpGemmArgs& a, hipStream_t stream) {
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm_bf16_nt_v6_kernel<TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    gemm_bf16_nt_v6_kernel<TAG><<<tiles, 512, LDS_BYTES, stream>>>(a);
+    MEDP_LAUNCH_CHECK("medp_gemm_bf16_nt(v6)");
+    return 0;
+}
+
+}  // namespace
+
+int medp_gemm_v6_launch(const MedpGemmArgs& a, int tag, void* stream) {
+    return tag == 1 ? launch_v6<1>(a, (hipStream_t)stream) : launch_v6<0>(a, (hipStream_t)stream);
+}

@@ -11,3 +11,5 @@ struct MedpGemmArgs {
     int ldr, act, out_bf16;
 };
 int medp_gemm_v4_launch(const MedpGemmArgs& a, int tag, void* stream);
+int medp_gemm_v5_launch(const MedpGemmArgs& a, int tag, void* stream);
+int medp_gemm_v6_launch(const MedpGemmArgs& a, int tag, void* stream);

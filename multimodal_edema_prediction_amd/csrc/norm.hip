@@ -52,6 +52,54 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     }
 }
 
+// Register-resident variant for D == 256*NV (ViT: NV=3, perceiver: NV=1): each lane keeps its NV float4 of the row, so the
+// row crosses the memory pipeline exactly once.  Same per-lane summation order as the generic kernel (bit-identical).
+template <bool OUT_BF16, int NV>
+__global__ __launch_bounds__(256) void layernorm_fwd_reg_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                                const float* __restrict__ b, void* __restrict__ y, int ldy,
+                                                                float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                                int rows, float eps) {
+    constexpr int D = 256 * NV;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * ldx;
+    float4 v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = *(const float4*)(xr + 4 * (lane + 64 * j));
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    const float mean = wave_sum(s) / (float)D;
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const float a = v[j].x - mean, c = v[j].y - mean, d = v[j].z - mean, e = v[j].w - mean;
+        ss += (a * a + c * c) + (d * d + e * e);
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = lane + 64 * j;
+        const float4 ww = *(const float4*)(w + 4 * i);
+        const float4 bb = *(const float4*)(b + 4 * i);
+        const float o0 = (v[j].x - mean) * rstd * ww.x + bb.x, o1 = (v[j].y - mean) * rstd * ww.y + bb.y;
+        const float o2 = (v[j].z - mean) * rstd * ww.z + bb.z, o3 = (v[j].w - mean) * rstd * ww.w + bb.w;
+        if (OUT_BF16) {
+            uint2 o;
+            o.x = pack_bf2(o0, o1);
+            o.y = pack_bf2(o2, o3);
+            *(uint2*)((bf16_t*)y + (size_t)row * ldy + 4 * i) = o;
+        } else {
+            *(float4*)((float*)y + (size_t)row * ldy + 4 * i) = make_float4(o0, o1, o2, o3);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ LayerNorm bwd (dx)
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w
 __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x,
@@ -122,15 +170,25 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out_a,
                                                            float* __restrict__ out_b, int nchunk, int D) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= D) return;
+    // 64 columns x 4 chunk lanes per workgroup: the chunk loop is 4x shorter and its loads are independent
+    __shared__ float red[2][4][64];
+    const int cl = threadIdx.x & 63, kl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float a = 0.f, b = 0.f;
-    for (int k = 0; k < nchunk; ++k) {
-        if (out_a) a += partial[(size_t)k * D + c];
-        b += partial[(size_t)(nchunk + k) * D + c];
+    if (c < D) {
+#pragma unroll 4
+        for (int k = kl; k < nchunk; k += 4) {
+            if (out_a) a += partial[(size_t)k * D + c];
+            b += partial[(size_t)(nchunk + k) * D + c];
+        }
     }
-    if (out_a) out_a[c] = a;
-    if (out_b) out_b[c] = b;
+    red[0][kl][cl] = a;
+    red[1][kl][cl] = b;
+    __syncthreads();
+    if (kl == 0 && c < D) {
+        if (out_a) out_a[c] = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+        if (out_b) out_b[c] = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ ScaleNorm
@@ -216,10 +274,19 @@ extern "C" int medp_layernorm_fwd(const float* x, int ldx, const float* w, const
     MEDP_CHECK_ARG(x && w && b && y, "layernorm_fwd: null operand");
     MEDP_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "layernorm_fwd: D, ldx, ldy must be multiples of 4");
     dim3 grid((rows + 3) / 4);
-    if (y_bf16)
-        layernorm_fwd_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, w, b, y, ldy, mean, rstd, rows, D, eps);
+    hipStream_t s = (hipStream_t)stream;
+    if (D == 768 && y_bf16)
+        layernorm_fwd_reg_kernel<true, 3><<<grid, 256, 0, s>>>(x, ldx, w, b, y, ldy, mean, rstd, rows, eps);
+    else if (D == 768)
+        layernorm_fwd_reg_kernel<false, 3><<<grid, 256, 0, s>>>(x, ldx, w, b, y, ldy, mean, rstd, rows, eps);
+    else if (D == 256 && y_bf16)
+        layernorm_fwd_reg_kernel<true, 1><<<grid, 256, 0, s>>>(x, ldx, w, b, y, ldy, mean, rstd, rows, eps);
+    else if (D == 256)
+        layernorm_fwd_reg_kernel<false, 1><<<grid, 256, 0, s>>>(x, ldx, w, b, y, ldy, mean, rstd, rows, eps);
+    else if (y_bf16)
+        layernorm_fwd_kernel<true><<<grid, 256, 0, s>>>(x, ldx, w, b, y, ldy, mean, rstd, rows, D, eps);
     else
-        layernorm_fwd_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, w, b, y, ldy, mean, rstd, rows, D, eps);
+        layernorm_fwd_kernel<false><<<grid, 256, 0, s>>>(x, ldx, w, b, y, ldy, mean, rstd, rows, D, eps);
     MEDP_LAUNCH_CHECK("medp_layernorm_fwd");
     return 0;
 }
@@ -241,7 +308,7 @@ extern "C" int medp_layernorm_bwd(const float* dy, int lddy, const float* x, int
         const int nchunk = colsum_chunks(rows), rpc = (rows + nchunk - 1) / nchunk;
         colsum_partial_kernel<1><<<dim3((D + 63) / 64, nchunk), 256, 0, s>>>(dy, lddy, x, ldx, mean, rstd, workspace, rows, D, rpc);
         MEDP_LAUNCH_CHECK("medp_layernorm_bwd(partial)");
-        colsum_final_kernel<<<(D + 255) / 256, 256, 0, s>>>(workspace, dw, db, nchunk, D);
+        colsum_final_kernel<<<(D + 63) / 64, 256, 0, s>>>(workspace, dw, db, nchunk, D);
         MEDP_LAUNCH_CHECK("medp_layernorm_bwd(final)");
     }
     return 0;
@@ -253,7 +320,7 @@ extern "C" int medp_colsum_f32(const float* x, int ldx, float* out, float* works
     const int nchunk = colsum_chunks(rows), rpc = (rows + nchunk - 1) / nchunk;
     colsum_partial_kernel<0><<<dim3((D + 63) / 64, nchunk), 256, 0, s>>>(x, ldx, nullptr, 0, nullptr, nullptr, workspace, rows, D, rpc);
     MEDP_LAUNCH_CHECK("medp_colsum_f32(partial)");
-    colsum_final_kernel<<<(D + 255) / 256, 256, 0, s>>>(workspace, nullptr, out, nchunk, D);
+    colsum_final_kernel<<<(D + 63) / 64, 256, 0, s>>>(workspace, nullptr, out, nchunk, D);
     MEDP_LAUNCH_CHECK("medp_colsum_f32(final)");
     return 0;
 }

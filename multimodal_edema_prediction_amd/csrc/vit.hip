@@ -20,10 +20,12 @@ VitWs plan(const MedpVitWeights* w, int B, int H, int W) {
     s.patch = off; off += al((size_t)B * P * D * 4);
     s.pos = off;   off += al(S * D * 4);
     s.x = off;     off += al(M * D * 4);
-    s.h = off;     off += al(M * D * 2);
-    s.qkv = off;   off += al(M * 3 * D * 2);
-    s.att = off;   off += al(M * D * 2);
-    s.f = off;     off += al(M * (size_t)w->mlp_hidden * 2);
+    // The block loop's activations are aliased so that its whole working set (x 50 MB + h 25 MB + max(qkv, f) 101 MB at
+    // B = 64, 224 px) stays inside the 256-MB Infinity Cache: att (attention output) takes the place of h (the LN1 output,
+    // dead once qkv is computed; LN2 rewrites it after proj has consumed att), and f (the MLP hidden) overlays qkv (dead
+    // after attention).  With separate buffers (277 MB) every GEMM epilogue burst went to HBM.
+    s.h = off;     s.att = off;  off += al(M * D * 2);
+    s.qkv = off;   s.f = off;    off += al(M * (size_t)(3 * D > (size_t)w->mlp_hidden ? 3 * D : (size_t)w->mlp_hidden) * 2);
     s.total = off;
     return s;
 }
