@@ -204,7 +204,7 @@ def main():
                    "gflop_per_sample": GFLOP_PER_SAMPLE, "step_mfma_fraction_of_peak": round(value * GFLOP_PER_SAMPLE / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
                    "last_loss": round(float(last["loss"]), 5), "batch_location": "host" if args.host_batch else "hbm",
                    "execution": "eager (engine.py from Python)" if args.eager else "captured HIP graph replay (graph_step.py)"},
-        "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_v3_kernel<1> (CXR-encoder block GEMMs: qkv/proj/fc1/fc2; 256x128x32 tiles, 128x64 per wave)",
+        "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_v6_kernel<1> (CXR-encoder block GEMMs: qkv/proj/fc1/fc2; 256x256x64 tiles, 8 waves ping-pong, 128x64 per wave)",
                      "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                      "traffic": traffic, "launches": int(n_l.value),
                      "avg_launch_us": round(ms.value * 1e3 / max(n_l.value, 1), 2),

@@ -8,6 +8,7 @@ typedef uint16_t bf16_t;                                            // raw bf16 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;           // 8 bf16 = one MFMA A/B fragment (4 VGPRs)
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define MEDP_WAVE 64
@@ -52,8 +53,11 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     __bf16 b = (__bf16)f;
     return __builtin_bit_cast(bf16_t, b);
 }
+// two floats -> one dword of two bf16 with ONE v_cvt_pk_bf16_f32 (the scalar casts + shift + or cost four VALU ops)
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+    const bf2_t b = __builtin_convertvector((f32x2){lo, hi}, bf2_t);
+    return __builtin_bit_cast(uint32_t, b);
 }
 
 // ---- wave reductions (64 lanes) --------------------------------------------------------------------

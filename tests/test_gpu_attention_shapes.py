@@ -1,0 +1,23 @@
+"""CXR-encoder attention (head dim 64) over the sequence lengths that exercise every wave specialisation of the kernel:
+1 / 2 / 3 query subtiles per wave, idle waves, ragged key tails, and the multi-chunk path (S > 320).  Reference: the same
+softmax(QK^T/8)V in fp32 torch on the bf16 operands (Dinov2SelfAttention as called from the reference model :152-158)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B,S,H", [(2, 256, 2), (2, 257, 3), (2, 272, 2), (1, 320, 2), (1, 64, 2), (1, 100, 2), (1, 17, 1),
+                                   (1, 1, 2), (1, 400, 2), (1, 1297, 2)])
+def test_attn_dh64_shapes(B, S, H):
+    from multimodal_edema_prediction_amd import functional as Fn
+    torch.manual_seed(S)
+    D = H * 64
+    qkv = torch.randn(B * S, 3 * D, device="cuda").bfloat16()
+    o = Fn.attn_dh64(qkv, B, S, H, 0.125).float().view(B, S, H, 64)
+    q, k, v = [t.float().view(B, S, H, 64).permute(0, 2, 1, 3) for t in qkv.split(D, dim=1)]
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).permute(0, 2, 1, 3)
+    err = (o - ref).abs()
+    assert not torch.isnan(o).any()
+    # bf16 P and bf16 output: 1e-2 absolute on O(1) values
+    assert float(err.max()) < 1.5e-2, f"S={S}: max err {float(err.max()):.3e}"
