@@ -84,7 +84,29 @@ __device__ __forceinline__ float erf_fast(float x) {
     const float r = 1.0f - p * t * __expf(-ax * ax);
     return copysignf(r, x);
 }
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
+// exact-form GELU 0.5 x (1 + erf(x / sqrt 2)) for a PAIR of values, written so the compiler emits packed f32 ops
+// (v_pk_mul / v_pk_fma): per element 6 packed slots + v_exp + v_rcp instead of ~18 scalar VALU ops — the fused GELU was
+// 42 us of the 147-us fc1 GEMM.  With r = poly(t) * exp(-x^2/2) (A&S 7.1.26):  x > 0: x - x r / 2 ;  x <= 0: x r / 2, which
+// also avoids the 1 - (1 - r) cancellation for large |x|.
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+    const f32x2 ax = (f32x2){fabsf(x[0]), fabsf(x[1])};
+    const f32x2 u = x * 0.84932180028801904272f;                    // sqrt(log2(e) / 2):  exp(-x^2/2) = exp2(-u^2)
+    const f32x2 w = -(u * u);
+    const f32x2 e = (f32x2){__builtin_amdgcn_exp2f(w[0]), __builtin_amdgcn_exp2f(w[1])};
+    const f32x2 d = ax * 0.23164189224774112f + 1.0f;               // 1 + 0.3275911 |x| / sqrt 2
+    const f32x2 t = (f32x2){__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    f32x2 p = t * 1.061405429f + -1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t + -0.284496736f;
+    p = p * t + 0.254829592f;
+    const f32x2 h = (x * 0.5f) * (p * t * e);
+    return (f32x2){x[0] > 0.f ? x[0] - h[0] : h[0], x[1] > 0.f ? x[1] - h[1] : h[1]};
+}
+__device__ __forceinline__ f32x4 gelu_erf4(f32x4 v) {
+    const f32x2 a = gelu_erf2((f32x2){v[0], v[1]}), b = gelu_erf2((f32x2){v[2], v[3]});
+    return (f32x4){a[0], a[1], b[0], b[1]};
+}
+__device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2((f32x2){x, x})[0]; }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
     const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);

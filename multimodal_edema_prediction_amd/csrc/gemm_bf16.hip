@@ -142,8 +142,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const GemmParams p
                 v += b;
             }
             if (p.act == 1) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    v = gelu_erf4(v);
             }
             if (p.scale) {
                 const f32x4 sc = *(const f32x4*)(p.scale + n);
@@ -266,8 +265,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v2_kernel(const GemmParam
             f32x4 v = acc[i][j];
             if (p.bias) v += *(const f32x4*)(p.bias + n);
             if (p.act == 1) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    v = gelu_erf4(v);
             }
             if (p.scale) v *= *(const f32x4*)(p.scale + n);
             if (p.residual) v += *(const f32x4*)(p.residual + (size_t)m * p.ldr + n);
@@ -429,8 +427,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_v3_kernel(const GemmParam
             if (m < p.M && n < p.N) {
                 v += bias4;
                 if (p.act == 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    v = gelu_erf4(v);
                 }
                 v *= scale4;
                 if (p.residual) v += *(const f32x4*)(p.residual + (size_t)m * p.ldr + n);

@@ -161,8 +161,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_v4_kernel(const MedpGemmA
                     const size_t mm = ok ? (size_t)m : 0;
                     if (p.bias) v += *(const f32x4*)(p.bias + nn);
                     if (p.act == 1) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    v = gelu_erf4(v);
                     }
                     if (p.scale) v *= *(const f32x4*)(p.scale + nn);
                     if (p.residual) v += *(const f32x4*)(p.residual + mm * p.ldr + nn);

@@ -163,8 +163,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_nt_v5_kernel(const MedpGemmA
                 if (m < p.M && n < p.N) {
                     v += bias4;
                     if (p.act == 1) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    v = gelu_erf4(v);
                     }
                     v *= scale4;
                     if (p.residual) v += *(const f32x4*)(p.residual + (size_t)m * p.ldr + n);
