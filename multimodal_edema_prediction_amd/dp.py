@@ -117,13 +117,27 @@ class GradAllReducer:
         view.copy_(p.grad)
         p.grad = view                        # the optimiser reads the reduced values straight out of the bucket
         b["fired"].add(p)
+        if p.is_cuda:
+            # the teacher's backward runs on two HIP streams (main_architecture_duett.TeacherModel.forward): remember where
+            # this slice was packed so the launch can wait for packs made on the other stream
+            s = torch.cuda.current_stream(p.device)
+            ev = torch.cuda.Event()
+            ev.record(s)
+            b.setdefault("packs", {})[s.cuda_stream] = ev
         if len(b["fired"]) == len(b["slots"]):
             self._launch(b)
 
     def _launch(self, b) -> None:
         b["launched"] = True
         if self.world == 1:
+            b.pop("packs", None)
             return
+        packs = b.pop("packs", None)
+        if packs:
+            cur = torch.cuda.current_stream(b["flat"].device)
+            for sid, ev in packs.items():
+                if sid != cur.cuda_stream:
+                    cur.wait_event(ev)
         if self._avg_op is None:
             backend = dist.get_backend(self.group)
             self._avg_op = dist.ReduceOp.AVG if backend == "nccl" else dist.ReduceOp.SUM

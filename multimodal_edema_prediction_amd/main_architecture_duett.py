@@ -24,6 +24,22 @@ __all__ = ["DuettFeatureExtractor", "load_duett_backbone", "CXREncoder", "PatchD
            "TeacherModel", "StudentModel"]
 
 # dropout stream ids (one per dropout site; combined with a per-forward seed)
+import os as _os
+
+_OVERLAP = _os.environ.get("MEDP_OVERLAP", "1") != "0"
+_SIDE_STREAMS: dict = {}
+
+
+def _side_stream(device):
+    """One extra HIP stream per device for the time-series half of the teacher forward/backward."""
+    if device.type != "cuda":
+        return None
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 _SID = {"img_cross": 0, "img_self": 10, "ts_cross": 20, "ts_self": 30, "image_head": 40, "temporal_head": 41,
         "correction_head": 42, "student_head": 50}
 
@@ -124,45 +140,59 @@ class PatchDualPathologyPerceiver(nn.Module):
         return A.rowdot(h, seq[3].weight, seq[3].bias)
 
     def forward(self, ts_tokens, img_patches_proj, return_attn=False, ts_ablation="hourly_only", *, _img_skip: int = 0):
-        if ts_tokens.ndim != 3:
-            raise ValueError(f"ts_tokens must be [B, T+1, d_ts], got {tuple(ts_tokens.shape)}")
+        ts_selected = self._select_ts(ts_tokens, ts_ablation)
         B = ts_tokens.size(0)
-        if ts_ablation == "full":
-            ts_selected = ts_tokens
-        elif ts_ablation == "hourly_only":
-            ts_selected = ts_tokens[:, :-1, :]
-        elif ts_ablation == "rep_only":
-            ts_selected = ts_tokens[:, -1:, :]
-        else:
-            raise ValueError(f"unknown ts_ablation={ts_ablation!r}; expected one of "
-                             "{'full', 'hourly_only', 'rep_only'}")
         seed = A.next_seed() if self.training else 0
         q0 = _BroadcastRowsFn.apply(self.shared_queries, B)             # img_q == ts_q (model :602-603)
-        ts_kv = A.linear(ts_selected, self.ts_proj.weight, self.ts_proj.bias)
+        ts = self._ts_branch(ts_selected, q0, seed, return_attn)
+        im = self._img_branch(img_patches_proj, q0, seed, return_attn, _img_skip)
+        return self._fuse(im, ts, return_attn)
 
-        I, img_attn = self.img_cross(q0, img_patches_proj, True, _kv_skip=_img_skip, _shared_q=self.shared_queries, _seed=seed) \
-            if return_attn else (self.img_cross(q0, img_patches_proj, _kv_skip=_img_skip, _shared_q=self.shared_queries, _seed=seed), None)
-        I = self.img_self(I, I, _seed=seed)
+    # The image and time-series halves of the forward only meet in `_fuse`; TeacherModel runs `_ts_branch` (with the DuETT
+    # encoder in front of it) on a second HIP stream next to the CXR encoder's GEMMs.  Same arithmetic either way.
+    def _ts_branch(self, ts_selected, q0, seed, return_attn):
+        ts_kv = A.linear(ts_selected, self.ts_proj.weight, self.ts_proj.bias)
         T_tok, ts_attn = self.ts_cross(q0, ts_kv, True, _shared_q=self.shared_queries, _seed=seed) \
             if return_attn else (self.ts_cross(q0, ts_kv, _shared_q=self.shared_queries, _seed=seed), None)
         T_tok = self.ts_self(T_tok, T_tok, _seed=seed)
-
-        hi = self._head(I, self.image_head, seed, _SID["image_head"])
         ht = self._head(T_tok, self.temporal_head, seed, _SID["temporal_head"])
         ch = self.correction_head
         c = A.layer_norm(T_tok, ch[0].weight, ch[0].bias, ch[0].eps)
         c = A.linear(c, ch[1].weight, ch[1].bias)
         c = A.gelu_dropout(c, float(ch[3].p) if ch[3].training else 0.0, seed, _SID["correction_head"])
         ts_correction = A.rowdot(c, ch[4].weight, None)
+        return {"T_tok": T_tok, "ht": ht, "ts_correction": ts_correction, "ts_attn": ts_attn}
+
+    def _img_branch(self, img_patches_proj, q0, seed, return_attn, _img_skip):
+        I, img_attn = self.img_cross(q0, img_patches_proj, True, _kv_skip=_img_skip, _shared_q=self.shared_queries, _seed=seed) \
+            if return_attn else (self.img_cross(q0, img_patches_proj, _kv_skip=_img_skip, _shared_q=self.shared_queries, _seed=seed), None)
+        I = self.img_self(I, I, _seed=seed)
+        hi = self._head(I, self.image_head, seed, _SID["image_head"])
+        return {"I": I, "hi": hi, "img_attn": img_attn}
+
+    def _fuse(self, im, ts, return_attn):
+        I, T_tok, ts_correction = im["I"], ts["T_tok"], ts["ts_correction"]
         img_logits, ts_logits, scaled_correction, fusion_logits = A.FusionLogitsFn.apply(
-            hi, ht, ts_correction, self.image_label_bias, self.temporal_label_bias, self.beta)
+            im["hi"], ts["ht"], ts_correction, self.image_label_bias, self.temporal_label_bias, self.beta)
         out = {"img_logits": img_logits, "ts_logits": ts_logits, "fusion_logits": fusion_logits, "img_tokens": I,
                "ts_tokens": T_tok, "fusion_tokens": T_tok, "ts_correction": ts_correction,
                "scaled_correction": scaled_correction}
         if return_attn:
-            out["img_attn"] = img_attn
-            out["ts_attn"] = ts_attn
+            out["img_attn"] = im["img_attn"]
+            out["ts_attn"] = ts["ts_attn"]
         return out
+
+    def _select_ts(self, ts_tokens, ts_ablation):
+        if ts_tokens.ndim != 3:
+            raise ValueError(f"ts_tokens must be [B, T+1, d_ts], got {tuple(ts_tokens.shape)}")
+        if ts_ablation == "full":
+            return ts_tokens
+        if ts_ablation == "hourly_only":
+            return ts_tokens[:, :-1, :]
+        if ts_ablation == "rep_only":
+            return ts_tokens[:, -1:, :]
+        raise ValueError(f"unknown ts_ablation={ts_ablation!r}; expected one of "
+                         "{'full', 'hourly_only', 'rep_only'}")
 
 
 class TeacherModel(nn.Module):
@@ -208,14 +238,41 @@ class TeacherModel(nn.Module):
         if batch_size is None:
             batch_size = pixel_values.shape[0]
         x = (x_ts_list, x_static_list, bin_ends_list)
-        duett_in = self.duett.feats_to_input(x, batch_size)
-        ts_tokens = self.duett.encode(duett_in)                             # [B, T+1, D]
         if not self.patch_dual_pathology_mode:
             raise NotImplementedError("only patch_dual_pathology_mode is live in the reference at HEAD (SURVEY.md F6)")
-        # CXR tokens after the final LayerNorm as bf16 [B, P+1, d_img]; the class row is skipped inside the cross-attention
+        duett_in = self.duett.feats_to_input(x, batch_size)
+        pc = self.perceiver
+        B = pixel_values.shape[0]
+        seed = A.next_seed() if pc.training else 0
+        q0 = _BroadcastRowsFn.apply(pc.shared_queries, B)                   # shared by both branches (model :602-603)
+        # ---- time-series half on a side stream: DuETT encoder + ts_proj / ts_cross / ts_self / temporal + correction heads.
+        # It is hundreds of short launches that do not depend on the image; next to the CXR encoder's one-workgroup-per-CU
+        # GEMMs they fill otherwise idle issue slots.  autograd replays each node's backward on its forward stream, so the
+        # two halves of the backward overlap the same way.  MEDP_OVERLAP=0 runs everything on one stream.
+        cur = torch.cuda.current_stream()
+        side = _side_stream(pixel_values.device) if _OVERLAP else None
+        if side is not None:
+            side.wait_stream(cur)
+            for t in (q0,) + tuple(duett_in):
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(side)
+            with torch.cuda.stream(side):
+                ts_tokens = self.duett.encode(duett_in)                     # [B, T+1, D]
+                ts = pc._ts_branch(pc._select_ts(ts_tokens, "hourly_only"), q0, seed, return_attn)
+        else:
+            ts_tokens = self.duett.encode(duett_in)
+            ts = pc._ts_branch(pc._select_ts(ts_tokens, "hourly_only"), q0, seed, return_attn)
+        # ---- image half: CXR tokens after the final LayerNorm as bf16 [B, P+1, d_img]; the class row is skipped inside the
+        # cross-attention
         tokens16 = self.cxr.forward_bf16(pixel_values)
         img_proj_full = A.linear(tokens16, self.img_proj.weight, self.img_proj.bias)   # [B, P+1, d]
-        out = self.perceiver(ts_tokens, img_proj_full, return_attn=return_attn, _img_skip=1)
+        im = pc._img_branch(img_proj_full, q0, seed, return_attn, 1)
+        if side is not None:
+            cur.wait_stream(side)
+            for t in ts.values():
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(cur)
+        out = pc._fuse(im, ts, return_attn)
         result = {"main_logit": out["fusion_logits"][:, 0], "img_logits": out["img_logits"], "ts_logits": out["ts_logits"],
                   "fusion_logits": out["fusion_logits"], "ts_correction": out["ts_correction"],
                   "scaled_correction": out["scaled_correction"]}
