@@ -13,7 +13,10 @@
 //                  identically on both operands), so P never touches LDS.
 // The block body is straight-line code specialised on the wave's subtile count (a wave-uniform switch) and on
 // "full block" vs "ragged tail"; the softmax is max / fma / v_exp_f32 / add per score (scale folded into the fma, bare
-// hardware exp2), and the 4-lane max butterfly uses v_permlane16/32_swap (VALU) instead of ds_bpermute round trips.
+// hardware exp2, scalar f32 ops — see key_block), and the 4-lane max butterfly uses v_permlane16/32_swap (VALU) instead
+// of ds_bpermute round trips.
+#include <stdlib.h>
+
 #include "common.h"
 #include "medp_hip.h"
 
@@ -94,7 +97,7 @@ __device__ __forceinline__ void key_block(WaveState<NQW>& w, const char* sK, con
                     if (kt * 16 + kq * 4 + r >= nvalid) st[qs][kt][r] = -INFINITY;
         }
         // the softmax is the VALU-bound part of a dh = 64 head (about 2x the MFMA time): chained max -> v_max3_f32 (two
-        // scores per instruction), scale / shift and the row sum as packed pairs (v_pk_fma_f32, v_pk_add_f32)
+        // scores per instruction), scale folded into one fma per score, bare v_exp_f32
         float mx = fmaxf(st[qs][0][0], st[qs][0][1]);
         mx = fmaxf(fmaxf(mx, st[qs][0][2]), st[qs][0][3]);
 #pragma unroll
@@ -107,19 +110,24 @@ __device__ __forceinline__ void key_block(WaveState<NQW>& w, const char* sK, con
         const float mc = m_new * c;
         const float alpha = __builtin_amdgcn_exp2f(w.m_run[qs] * c - mc);
         w.m_run[qs] = m_new;
-        const f32x2 c2 = (f32x2){c, c}, nmc2 = (f32x2){-mc, -mc};
-        f32x2 ls2 = (f32x2){0.f, 0.f};
+        // Plain scalar fma / exp / add on purpose.  Written as packed pairs (v_pk_fma_f32 on the MFMA results, v_pk_add_f32
+        // on the fresh v_exp_f32 results) the same arithmetic was NOT bit-stable once other kernels shared the SIMD: about
+        // 1 % of launches returned a 16-query subtile off by ~1e-2 under the two-stream training step, none when the
+        // kernel ran alone (some issue-timing hazard around packed f32 consumers; the scalar form costs no time).
+        // tools/debug_determinism7.py / tests/test_gpu_bit_stability.py are the screens for it.
+        float ls = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; r += 2) {
-                const f32x2 t = (f32x2){st[qs][kt][r], st[qs][kt][r + 1]} * c2 + nmc2;
-                const f32x2 e = (f32x2){__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-                st[qs][kt][r] = e[0];
-                st[qs][kt][r + 1] = e[1];
-                ls2 += e;
+                const float e0 = __builtin_amdgcn_exp2f(fmaf(st[qs][kt][r], c, -mc));
+                const float e1 = __builtin_amdgcn_exp2f(fmaf(st[qs][kt][r + 1], c, -mc));
+                st[qs][kt][r] = e0;
+                st[qs][kt][r + 1] = e1;
+                ls += e0;
+                ls += e1;
             }
-        w.l_run[qs] = w.l_run[qs] * alpha + (ls2[0] + ls2[1]);
+        w.l_run[qs] = w.l_run[qs] * alpha + ls;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) w.o[qs][dt] *= alpha;
     }

@@ -26,7 +26,8 @@ __all__ = ["DuettFeatureExtractor", "load_duett_backbone", "CXREncoder", "PatchD
 # dropout stream ids (one per dropout site; combined with a per-forward seed)
 import os as _os
 
-_OVERLAP = _os.environ.get("MEDP_OVERLAP", "1") != "0"
+_OVERLAP_MODE = int(_os.environ.get("MEDP_OVERLAP", "1"))   # 0 = one stream, 1 = whole TS half beside the CXR encoder, 2 = DuETT encoder only
+_OVERLAP = _OVERLAP_MODE != 0
 _SIDE_STREAMS: dict = {}
 
 
@@ -258,7 +259,13 @@ class TeacherModel(nn.Module):
                     t.record_stream(side)
             with torch.cuda.stream(side):
                 ts_tokens = self.duett.encode(duett_in)                     # [B, T+1, D]
+                if _OVERLAP_MODE == 1:
+                    ts = pc._ts_branch(pc._select_ts(ts_tokens, "hourly_only"), q0, seed, return_attn)
+            if _OVERLAP_MODE != 1:                                          # encoder only on the side stream
+                cur.wait_stream(side)
+                ts_tokens.record_stream(cur)
                 ts = pc._ts_branch(pc._select_ts(ts_tokens, "hourly_only"), q0, seed, return_attn)
+                side = None
         else:
             ts_tokens = self.duett.encode(duett_in)
             ts = pc._ts_branch(pc._select_ts(ts_tokens, "hourly_only"), q0, seed, return_attn)
