@@ -31,10 +31,25 @@ struct SmallAttnParams {
     const uint32_t* epoch;
 };
 
+// <a, b> over dh floats: a in LDS (same address on every lane), b = this lane's own K / V row in global memory.  Rows are
+// contiguous, so the vector form reads them as float4 (4x fewer load instructions on what is a latency-bound kernel).
+__device__ __forceinline__ float dot_row(const float* __restrict__ a, const float* __restrict__ b, int dh, bool vec) {
+    float acc = 0.f;
+    if (vec) {
+        for (int d = 0; d < dh; d += 4) {
+            const float4 x = *(const float4*)(a + d), y = *(const float4*)(b + d);
+            acc += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+        }
+    } else {
+        for (int d = 0; d < dh; ++d) acc += a[d] * b[d];
+    }
+    return acc;
+}
+
 // scores + softmax for one query row; returns p (post-softmax, pre-dropout) per owned key in pj[], writes nothing
 template <int NPER>
 __device__ __forceinline__ void row_softmax(const SmallAttnParams& p, const float* qrow, const float* kbase, int lane,
-                                            float (&pj)[NPER]) {
+                                            float (&pj)[NPER], bool vec) {
     constexpr int nper = NPER;
     float mx = -INFINITY;
 #pragma unroll
@@ -42,10 +57,7 @@ __device__ __forceinline__ void row_softmax(const SmallAttnParams& p, const floa
         const int j = lane + 64 * i;
         float s = -INFINITY;
         if (j < p.Lk) {
-            const float* kr = kbase + (size_t)j * p.ldk;
-            float acc = 0.f;
-            for (int d = 0; d < p.dh; ++d) acc += qrow[d] * kr[d];
-            s = acc * p.scale;
+            s = dot_row(qrow, kbase + (size_t)j * p.ldk, p.dh, vec) * p.scale;
         }
         pj[i] = s;
         mx = fmaxf(mx, s);
@@ -73,13 +85,14 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(const SmallAttnPara
     float* sq = sm + 4 * p.Lk + wave * p.dh;
     const float* kbase = p.k + (size_t)b * p.kv_bs + h * p.dh;
     const float* vbase = p.v + (size_t)b * p.kv_bs + h * p.dh;
+    const bool vec = (((p.dh | p.ldk | p.ldv) & 3) == 0) && ((((uintptr_t)kbase | (uintptr_t)vbase) & 15) == 0);
     constexpr int nper = NPER;
     float pj[NPER];
     for (int qi = wave; qi < p.Lq; qi += 4) {
         const float* qr = p.q + (size_t)b * p.q_bs + (size_t)qi * p.ldq + h * p.dh;
         if (lane < p.dh) sq[lane] = qr[lane];
         WAVE_LDS_SYNC();
-        row_softmax<NPER>(p, sq, kbase, lane, pj);
+        row_softmax<NPER>(p, sq, kbase, lane, pj, vec);
 #pragma unroll
         for (int i = 0; i < nper; ++i) {
             const int j = lane + 64 * i;
@@ -121,6 +134,7 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const SmallAttnPara
     const float* vbase = p.v + (size_t)b * p.kv_bs + h * p.dh;
     float* dkbase = dk + (size_t)b * dkv_bs + h * p.dh;
     float* dvbase = dv + (size_t)b * dkv_bs + h * p.dh;
+    const bool vec = (((p.dh | p.ldk | p.ldv) & 3) == 0) && ((((uintptr_t)kbase | (uintptr_t)vbase) & 15) == 0);
     constexpr int nper = NPER;
     float pj[NPER];
 
@@ -136,7 +150,7 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const SmallAttnPara
             const int qi = c0 + ql;
             const float* qr = sQ + ql * p.dh;
             const float* dor = sDO + ql * p.dh;
-            row_softmax<NPER>(p, qr, kbase, lane, pj);
+            row_softmax<NPER>(p, qr, kbase, lane, pj, vec);
             // dP_j = <dO, V_j> * dropmask_j ; delta = sum_j P_j*dropmask_j*... (softmax bwd on the pre-dropout p)
             float dpj[NPER];
             float delta = 0.f;
@@ -145,8 +159,7 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const SmallAttnPara
                 const int j = lane + 64 * i;
                 float dp = 0.f, msk = 1.f;
                 if (j < p.Lk) {
-                    const float* vr = vbase + (size_t)j * p.ldv;
-                    for (int d = 0; d < p.dh; ++d) dp += dor[d] * vr[d];
+                    dp = dot_row(dor, vbase + (size_t)j * p.ldv, p.dh, vec);
                     if (p.drop_p > 0.f) msk = dropout_scale(medp_mix_epoch(p.seed, p.epoch), p.stream_id, ((uint32_t)(b * p.H + h) * p.Lq + qi) * p.Lk + j, p.drop_p, p.inv_keep);
                     dp *= msk;
                     sP[ql * p.Lk + j] = pj[i] * msk;          // dropped-out weights multiply V in forward

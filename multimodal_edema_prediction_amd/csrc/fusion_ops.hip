@@ -52,31 +52,45 @@ __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float* __restrict
     if (lane == 0) y[row] = a + (b ? b[0] : 0.f);
 }
 // dx[m,c] = dy[m]*w[c] ; dw[c] = sum_m dy[m]*x[m,c] ; db = sum_m dy[m]
-// grid = ceil(D/64) blocks of 64 columns x 4 row-lanes (block 0 also writes db); dx written by all blocks, row-strided
-__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, int ldx,
-                                                         const float* __restrict__ w, float* __restrict__ dx, float* __restrict__ dw,
-                                                         float* __restrict__ db, int rows, int D) {
-    __shared__ float red[4][64];
+// grid = ceil(D/64) blocks of 64 columns x 16 row-lanes (block 0 also writes db).  The heads have D = 64 and rows = B*K = 448,
+// i.e. ONE block: 16 row-lanes (1024 threads) keep the per-thread chain at 28 dependent iterations instead of 112 (48 -> ~12 us,
+// on the serial tail of the step behind the CXR encoder).
+__global__ __launch_bounds__(1024) void rowdot_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, int ldx,
+                                                          const float* __restrict__ w, float* __restrict__ dx, float* __restrict__ dw,
+                                                          float* __restrict__ db, int rows, int D) {
+    __shared__ float red[16][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
-    float a = 0.f, bs = 0.f;
+    float a = 0.f;
     if (c < D) {
         const float wc = w[c];
-        for (int m = rl; m < rows; m += 4) {
+#pragma unroll 4
+        for (int m = rl; m < rows; m += 16) {
             const float g = dy[m];
             dx[(size_t)m * D + c] = g * wc;
             a += g * x[(size_t)m * ldx + c];
         }
     }
-    if (blockIdx.x == 0 && cl == 0)
-        for (int m = rl; m < rows; m += 4) bs += dy[m];
     red[rl][cl] = a;
     __syncthreads();
-    if (rl == 0 && c < D) dw[c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
-    __syncthreads();
+    if (rl == 0 && c < D) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cl];
+        dw[c] = t;
+    }
     if (db && blockIdx.x == 0) {
-        if (cl == 0) red[rl][0] = bs;
         __syncthreads();
-        if (threadIdx.x == 0) db[0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        float bs = 0.f;
+        for (int m = threadIdx.x; m < rows; m += 1024) bs += dy[m];
+        bs = wave_sum(bs);
+        if (cl == 0) red[0][rl] = bs;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[0][k];
+            db[0] = t;
+        }
     }
 }
 
@@ -340,7 +354,7 @@ extern "C" int medp_rowdot_fwd(const float* x, int ldx, const float* w, const fl
 extern "C" int medp_rowdot_bwd(const float* dy, const float* x, int ldx, const float* w, float* dx, float* dw, float* db, int rows,
                                int D, void* stream) {
     MEDP_CHECK_ARG(dy && x && w && dx && dw && rows > 0 && D > 0, "rowdot_bwd: bad argument");
-    rowdot_bwd_kernel<<<(D + 63) / 64, 256, 0, (hipStream_t)stream>>>(dy, x, ldx, w, dx, dw, db, rows, D);
+    rowdot_bwd_kernel<<<(D + 63) / 64, 1024, 0, (hipStream_t)stream>>>(dy, x, ldx, w, dx, dw, db, rows, D);
     MEDP_LAUNCH_CHECK("medp_rowdot_bwd");
     return 0;
 }
