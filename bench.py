@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (weak scaling, accelerate semantics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="graph mode: run the frozen CXR encoder inside its own batch's step instead of one batch ahead")
     ap.add_argument("--host-batch", action="store_true", help="keep batches on the host: PCIe-inclusive rate (never `value`)")
     ap.add_argument("--eager", action="store_true", help="run the step eagerly from Python (engine.py) instead of replaying the captured HIP graph")
     args = ap.parse_args()
@@ -134,14 +136,15 @@ def main():
         if force_pg and not torch.distributed.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
             torch.distributed.init_process_group("nccl", rank=0, world_size=1)
-        gstep = GraphedTeacherStep(teacher, loss_fn, opt, pool[0], device, world=2 if force_pg else world)
+        gstep = GraphedTeacherStep(teacher, loss_fn, opt, pool[0], device, world=2 if force_pg else world,
+                                   pipeline_cxr=not args.no_pipeline)
         if force_pg:
             gstep.world = 1
             _ar = gstep._allreduce
             gstep._allreduce = lambda: torch.distributed.all_reduce(gstep.flat_grad, op=torch.distributed.ReduceOp.AVG)
 
         def step(i):
-            out = gstep.step(pool[i % n_pool])
+            out = gstep.step(pool[i % n_pool], pool[(i + 1) % n_pool])     # (batch to train on, batch the next call will bring)
             sched.step()
             return {"loss": out["loss"].item()}          # one host read per step, like the reference's per-step logging
 
@@ -203,7 +206,10 @@ def main():
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "gflop_per_sample": GFLOP_PER_SAMPLE, "step_mfma_fraction_of_peak": round(value * GFLOP_PER_SAMPLE / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
                    "last_loss": round(float(last["loss"]), 5), "batch_location": "host" if args.host_batch else "hbm",
-                   "execution": "eager (engine.py from Python)" if args.eager else "captured HIP graph replay (graph_step.py)"},
+                   "execution": "eager (engine.py from Python)" if args.eager else (
+                       "captured HIP graph replay (graph_step.py), two-stream step" if args.no_pipeline else
+                       "captured HIP graph replay (graph_step.py): two-stream step + frozen CXR encoder of batch k+1 run beside the "
+                       "step of batch k (one encoder forward, one fusion fwd/bwd and one update per replay; 4 distinct batches rotate)")},
         "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_v6_kernel<1> (CXR-encoder block GEMMs: qkv/proj/fc1/fc2; 256x256x64 tiles, 8 waves ping-pong, 128x64 per wave)",
                      "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                      "traffic": traffic, "launches": int(n_l.value),

@@ -8,6 +8,14 @@ RNG epoch (`medp_rng_set_epoch_ptr`), the optimiser step count (`FusedAdamW.dev_
 
 N > 1: forward+backward are one graph accumulating into a flat fp32 gradient arena, the arena is all-reduced by RCCL
 between the two replays (one collective, 14.8 MB), and the optimiser is a second graph.
+
+`pipeline_cxr=True` (software pipelining across steps): the CXR encoder is frozen, so its tokens for batch k+1 depend on
+nothing the training step of batch k produces.  The captured step then holds THREE parallel branches: the image half +
+backward + optimiser of batch k (reading the tokens the previous replay left in `tok_cur`), the time-series half on the
+side stream, and the encoder forward of batch k+1 on a third stream; the replay ends by moving the new tokens into
+`tok_cur`.  Every replay still runs exactly one encoder forward, one fusion forward/backward and one update — the
+encoder pass is just shifted one batch ahead (the first batch's pass happens in `prime`).  Results are bit-identical to the
+unpipelined step (tests/test_gpu_pipeline.py).
 """
 from __future__ import annotations
 
@@ -20,7 +28,7 @@ from .abi import check, lib, ptr, stream
 
 class GraphedTeacherStep:
     def __init__(self, teacher, loss_fn, optimizer, example_batch: dict, device, world: int = 1, group=None, warmup: int = 3,
-                 split: bool = False, before_capture=None):
+                 split: bool = False, before_capture=None, pipeline_cxr: bool = False):
         self.teacher, self.loss_fn, self.opt, self.device, self.world, self.group = teacher, loss_fn, optimizer, device, world, group
         b = engine._move_lists(example_batch, device)
         # static input buffers; the per-sample tuples the model interface wants are views into the stacked buffers
@@ -28,6 +36,15 @@ class GraphedTeacherStep:
         self.x_static = torch.stack(b["x_static"]).contiguous()
         self.bin_ends = torch.stack(b["bin_ends"]).contiguous()
         self.pixels = b["pixel_values"].clone()
+        self.pipeline = bool(pipeline_cxr)
+        if self.pipeline:
+            if any(p.requires_grad for p in teacher.cxr.parameters()):
+                raise ValueError("pipeline_cxr needs a frozen CXR encoder")
+            self.pixels_next = self.pixels.clone()
+            self.vit_stream = torch.cuda.Stream(device=device)
+            with torch.no_grad():
+                self.tok_cur = teacher.cxr.forward_bf16(self.pixels).clone()
+            self._expect = None        # id() of the batch whose tokens sit in tok_cur
         self.y_multi = b["y_multi"].clone().float()
         self.y_mask = b["y_multi_mask"].clone().float()
         self.epoch = torch.zeros(1, dtype=torch.int32, device=device)
@@ -88,10 +105,21 @@ class GraphedTeacherStep:
 
     def _fwd_bwd(self):
         B = self.x_ts.shape[0]
+        tok_next = None
+        if self.pipeline:
+            cur = torch.cuda.current_stream(self.device)
+            self.vit_stream.wait_stream(cur)
+            with torch.cuda.stream(self.vit_stream), torch.no_grad():
+                tok_next = self.teacher.cxr.forward_bf16(self.pixels_next)          # batch k+1, beside batch k's step
         out = self.teacher(tuple(self.x_ts[i] for i in range(B)), tuple(self.x_static[i] for i in range(B)),
-                           tuple(self.bin_ends[i] for i in range(B)), self.pixels)
+                           tuple(self.bin_ends[i] for i in range(B)), self.pixels,
+                           **({"_cxr_tokens16": self.tok_cur} if self.pipeline else {}))
         losses = self.loss_fn(out["img_logits"], out["ts_logits"], out["fusion_logits"], self.y_multi, self.y_mask)
         losses["total"].backward()
+        if self.pipeline:
+            cur.wait_stream(self.vit_stream)
+            tok_next.record_stream(cur)
+            self.tok_cur.copy_(tok_next)          # after the backward: the weight-gradient GEMM of img_proj reads tok_cur
         return {"loss": losses["total"].detach(), "img_total": losses["img_total"], "ts_total": losses["ts_total"],
                 "fus_total": losses["fus_total"], "fusion_logits": out["fusion_logits"].detach(), "main_logit": out["main_logit"].detach()}
 
@@ -103,19 +131,35 @@ class GraphedTeacherStep:
                 self.flat_grad.div_(self.world)
 
     # ---- one training step --------------------------------------------------------------------------------------------------
+    def prime(self, batch: dict) -> None:
+        """Pipelined mode: run the CXR encoder for `batch` now, so the next `step(batch, ...)` finds its tokens."""
+        with torch.no_grad():
+            self.tok_cur.copy_(self.teacher.cxr.forward_bf16(batch["pixel_values"].to(self.device, non_blocking=True)))
+        self._expect = id(batch)
+
     def load_batch(self, batch: dict) -> None:
         """Copy a batch (host or device) into the static input buffers (async on the current stream)."""
         self.x_ts.copy_(torch.stack(tuple(batch["x_ts"])), non_blocking=True)
         self.x_static.copy_(torch.stack(tuple(batch["x_static"])), non_blocking=True)
         self.bin_ends.copy_(torch.stack(tuple(batch["bin_ends"])), non_blocking=True)
-        self.pixels.copy_(batch["pixel_values"], non_blocking=True)
+        if not self.pipeline:                        # pipelined: this batch's pixels were consumed by the previous replay
+            self.pixels.copy_(batch["pixel_values"], non_blocking=True)
         self.y_multi.copy_(batch["y_multi"], non_blocking=True)
         self.y_mask.copy_(batch["y_multi_mask"], non_blocking=True)
 
-    def step(self, batch: dict | None = None) -> dict:
-        """Replay the captured step; returns device tensors (no host sync — read them with .item() when needed)."""
+    def step(self, batch: dict | None = None, next_batch: dict | None = None) -> dict:
+        """Replay the captured step; returns device tensors (no host sync — read them with .item() when needed).
+        Pipelined mode: `next_batch` is the batch the NEXT call will train on (its CXR tokens are produced by this replay);
+        if the caller breaks that promise the tokens are recomputed on the spot."""
         if batch is not None:
             self.load_batch(batch)
+        if self.pipeline:
+            if batch is not None and self._expect != id(batch):
+                self.prime(batch)
+            nb = next_batch if next_batch is not None else batch
+            if nb is not None:
+                self.pixels_next.copy_(nb["pixel_values"], non_blocking=True)
+                self._expect = id(nb)
         self.opt.refresh_lrs()                       # learning rates of this step (scheduler) -> pinned descriptor table
         self.g_fb.replay()
         if self.g_opt is not None:

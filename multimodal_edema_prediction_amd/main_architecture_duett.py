@@ -235,7 +235,9 @@ class TeacherModel(nn.Module):
                                       "at HEAD (model file :659-741); SURVEY.md §8f-2")
 
     def forward(self, x_ts_list, x_static_list, bin_ends_list, pixel_values: torch.Tensor, batch_size: Optional[int] = None,
-                return_attn: bool = False):
+                return_attn: bool = False, *, _cxr_tokens16: Optional[torch.Tensor] = None):
+        """`_cxr_tokens16` (bf16 [B, P+1, d_img], private): tokens of the FROZEN CXR encoder for `pixel_values`, computed
+        ahead of time — graph_step.py runs the encoder for the next batch beside this batch's training step."""
         if batch_size is None:
             batch_size = pixel_values.shape[0]
         x = (x_ts_list, x_static_list, bin_ends_list)
@@ -271,7 +273,12 @@ class TeacherModel(nn.Module):
             ts = pc._ts_branch(pc._select_ts(ts_tokens, "hourly_only"), q0, seed, return_attn)
         # ---- image half: CXR tokens after the final LayerNorm as bf16 [B, P+1, d_img]; the class row is skipped inside the
         # cross-attention
-        tokens16 = self.cxr.forward_bf16(pixel_values)
+        if _cxr_tokens16 is not None:
+            if any(p.requires_grad for p in self.cxr.parameters()):
+                raise ValueError("_cxr_tokens16 is only valid with a frozen CXR encoder")
+            tokens16 = _cxr_tokens16
+        else:
+            tokens16 = self.cxr.forward_bf16(pixel_values)
         img_proj_full = A.linear(tokens16, self.img_proj.weight, self.img_proj.bias)   # [B, P+1, d]
         im = pc._img_branch(img_proj_full, q0, seed, return_attn, 1)
         if side is not None:

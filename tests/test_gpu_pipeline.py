@@ -1,0 +1,41 @@
+"""Software pipelining of the frozen CXR encoder across steps (graph_step.GraphedTeacherStep(pipeline_cxr=True)): the encoder
+forward of batch k+1 runs beside the training step of batch k.  It must change nothing numerically: same losses and the
+same parameters, bit for bit, as the unpipelined captured step over a sequence of DISTINCT batches, including when the
+caller breaks the announced order."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def test_pipelined_step_is_bit_identical():
+    import test_gpu_model as T
+    from multimodal_edema_prediction_amd.graph_step import GraphedTeacherStep
+    from multimodal_edema_prediction_amd.losses_duett import DualPathologyLoss
+    from multimodal_edema_prediction_amd.optim import FusedAdamW, make_param_groups
+    dev = torch.device("cuda")
+    loss_fn = DualPathologyLoss(torch.ones(T.K), None, 0.5, 0.5, 1.0).to(dev)
+    start = T.META["teacher_batch_start"]
+    batches = [T.make_batch(T.CCFG, start + 97 * i, T.B, mode="teacher") for i in range(4)]
+    assert not torch.equal(batches[0]["pixel_values"], batches[1]["pixel_values"])
+    order = [0, 1, 2, 3, 0, 2, 1]                     # position 5 breaks the announced order on purpose (announced 1, got 2)
+    announce = [1, 2, 3, 0, 1, 1, 0]
+
+    def run(pipeline):
+        te = T.build_teacher()
+        opt = FusedAdamW(make_param_groups(te, 8e-5), weight_decay=5e-2)
+        gs = GraphedTeacherStep(te, loss_fn, opt, batches[0], dev, warmup=2, pipeline_cxr=pipeline)
+        losses = [float(gs.step(batches[k], batches[n])["loss"].item()) for k, n in zip(order, announce)]
+        return losses, {k: p.detach().clone() for k, p in te.named_parameters() if p.requires_grad}
+
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    np.testing.assert_array_equal(np.array(l1), np.array(l0))
+    assert len(set(l0)) > 3                            # the batches really differ
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
