@@ -52,16 +52,30 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v6_kernel(const MedpGemmA
     const bf16_t* zero = (const bf16_t*)g_zero16_v6;
 
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int nwg = tiles_m * tiles_n;
     const int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    constexpr int MB = 8, SN = 4;                      // band / super-column order, see v3
-    const int band = wg / (MB * tiles_n), rb = wg % (MB * tiles_n);
-    const int mb = min(MB, tiles_m - band * MB);
-    const int sc = rb / (mb * SN), r2 = rb % (mb * SN);
-    const int sn = min(SN, tiles_n - sc * SN);
-    const int m0 = (band * MB + r2 / sn) * BM, n0 = (sc * SN + r2 % sn) * BN;
+    // Block -> tile.  Workgroups are dispatched in index order, block b to XCD b % 8, one per CU (32 CUs per XCD).  The
+    // FULL row-tiles come first: XCD x gets a contiguous run of them (band x super-column order inside, see v3) so its L2 sees
+    // few panels; the cheap tiles of a ragged last row (M = 64 * 257: 64 live rows, three quarters of their MFMAs skipped)
+    // take the highest indices, i.e. they are dispatched LAST.  fc1 (768 full + 12 ragged tiles) is then 96 full tiles =
+    // exactly 3 rounds per XCD plus a short ragged tail, instead of a fourth round that holds one full tile per XCD.
+    const int rag = (p.M % BM) ? 1 : 0;
+    const int tm_full = tiles_m - rag;
+    const int nfull = tm_full * tiles_n;
+    const int full8 = nfull & ~7;                      // full tiles dealt in runs of nfull/8 per XCD; the rest by index
+    int m0, n0;
+    if (bid < nfull) {
+        const int wg = bid < full8 ? (bid & 7) * (full8 >> 3) + (bid >> 3) : bid;   // the < 8 leftover full tiles keep their index
+        constexpr int MB = 8, SN = 4;
+        const int band = wg / (MB * tiles_n), rb = wg % (MB * tiles_n);
+        const int mb = min(MB, tm_full - band * MB);
+        const int sc = rb / (mb * SN), r2 = rb % (mb * SN);
+        const int sn = min(SN, tiles_n - sc * SN);
+        m0 = (band * MB + r2 / sn) * BM;
+        n0 = (sc * SN + r2 % sn) * BN;
+    } else {                                           // the ragged row, one tile per column
+        m0 = tm_full * BM;
+        n0 = (bid - nfull) * BN;
+    }
     const int nkt = (p.K + 63) >> 6;
 
     // ---- LDS-DMA staging: half-tile = 128 rows x 8 chunks; lane's two pieces are rows (tid>>3) and (tid>>3)+64 ------
