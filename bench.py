@@ -223,7 +223,7 @@ def main():
     else:
         res["cpu_baseline"] = None
     print(json.dumps(res), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -13,7 +13,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def test_pipelined_step_is_bit_identical():
+@pytest.mark.parametrize("split", [False, True])
+def test_pipelined_step_is_bit_identical(split):
     import test_gpu_model as T
     from multimodal_edema_prediction_amd.graph_step import GraphedTeacherStep
     from multimodal_edema_prediction_amd.losses_duett import DualPathologyLoss
@@ -29,11 +30,11 @@ def test_pipelined_step_is_bit_identical():
     def run(pipeline):
         te = T.build_teacher()
         opt = FusedAdamW(make_param_groups(te, 8e-5), weight_decay=5e-2)
-        gs = GraphedTeacherStep(te, loss_fn, opt, batches[0], dev, warmup=2, pipeline_cxr=pipeline)
+        gs = GraphedTeacherStep(te, loss_fn, opt, batches[0], dev, warmup=2, pipeline_cxr=pipeline, split=split)
         losses = [float(gs.step(batches[k], batches[n])["loss"].item()) for k, n in zip(order, announce)]
         return losses, {k: p.detach().clone() for k, p in te.named_parameters() if p.requires_grad}
 
-    l0, p0 = run(False)
+    l0, p0 = run(False)          # split=True is the N > 1 arrangement: separate forward/backward, optimiser and encoder graphs
     l1, p1 = run(True)
     np.testing.assert_array_equal(np.array(l1), np.array(l0))
     assert len(set(l0)) > 3                            # the batches really differ
