@@ -29,6 +29,9 @@ import os as _os
 _OVERLAP_MODE = int(_os.environ.get("MEDP_OVERLAP", "1"))   # 0 = one stream, 1 = whole TS half beside the CXR encoder, 2 = DuETT encoder only
 _OVERLAP = _OVERLAP_MODE != 0
 _SIDE_STREAMS: dict = {}
+if _OVERLAP and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+    # `shared_queries` feeds both halves of the forward, so its AccumulateGrad node legitimately sees producers on two streams
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
 
 
 def _side_stream(device):
