@@ -89,6 +89,9 @@ def main():
                     help="graph mode: run the frozen CXR encoder inside its own batch's step instead of one batch ahead")
     ap.add_argument("--host-batch", action="store_true", help="keep batches on the host: PCIe-inclusive rate (never `value`)")
     ap.add_argument("--eager", action="store_true", help="run the step eagerly from Python (engine.py) instead of replaying the captured HIP graph")
+    ap.add_argument("--stress", action="store_true",
+                    help="BASELINE.json configs[4] shapes per GPU (CXR 512x512, T=256, F=96, batch 32 = 256 / 8 GPUs) instead of the "
+                         "metric's configs[2]; a side measurement, never the contract line")
     args = ap.parse_args()
 
     from multimodal_edema_prediction_amd import abi, dp, engine
@@ -109,7 +112,11 @@ def main():
     device = torch.device("cuda", local)
 
     T, V, DS, K, B = 96, 48, 8, 7, args.batch
-    ccfg = CohortCfg(n_timesteps=T, n_vars=V, d_static=DS, image_size=224, n_labels=K, seed=1234)
+    img = 224
+    if args.stress:
+        T, V, img = 256, 96, 512
+        B = 32 if args.batch == 64 else args.batch
+    ccfg = CohortCfg(n_timesteps=T, n_vars=V, d_static=DS, image_size=img, n_labels=K, seed=1234)
     teacher = build_teacher(T, V, DS, K, device)
     dp.broadcast_parameters(teacher)
     loss_fn = DualPathologyLoss(torch.ones(K), None, 0.5, 0.5, 1.0).to(device)
@@ -200,11 +207,14 @@ def main():
         "metric": "multimodal train samples/sec", "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "BASELINE.json configs[2]: full multimodal teacher (main_train_teacher_duett, perceiver_type=dual_patch, "
-                               "--freeze_duett, frozen CXR): CXR 224x224 ViT-B/14 + DuETT T=96/F=48, batch 64 per GPU, bf16 MFMA / fp32 "
-                               "accumulate, random-init weights, synthetic cohort seed 1234, perceiver dropout 0.2 ON",
+        "config": {"workload": ("BASELINE.json configs[4] shapes (STRESS side measurement, not the metric's configuration): full multimodal "
+                                f"teacher, CXR {img}x{img} ViT-B/14 + DuETT T={T}/F={V}, batch {B} per GPU" if args.stress else
+                                "BASELINE.json configs[2]: full multimodal teacher (main_train_teacher_duett, perceiver_type=dual_patch, "
+                                "--freeze_duett, frozen CXR): CXR 224x224 ViT-B/14 + DuETT T=96/F=48, batch 64 per GPU, bf16 MFMA / fp32 "
+                                "accumulate, random-init weights, synthetic cohort seed 1234, perceiver dropout 0.2 ON"),
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                   "gflop_per_sample": GFLOP_PER_SAMPLE, "step_mfma_fraction_of_peak": round(value * GFLOP_PER_SAMPLE / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
+                   "gflop_per_sample": None if args.stress else GFLOP_PER_SAMPLE,
+                   "step_mfma_fraction_of_peak": None if args.stress else round(value * GFLOP_PER_SAMPLE / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
                    "last_loss": round(float(last["loss"]), 5), "batch_location": "host" if args.host_batch else "hbm",
                    "execution": "eager (engine.py from Python)" if args.eager else (
                        "captured HIP graph replay (graph_step.py), two-stream step" if args.no_pipeline else
@@ -216,7 +226,7 @@ def main():
                      "avg_launch_us": round(ms.value * 1e3 / max(n_l.value, 1), 2),
                      "algorithmic_flops_per_launch": round(fl.value / max(n_l.value, 1), 1)},
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not args.stress:
         nb = 4
         cb = make_batch(ccfg, start=10_000, batch_size=nb, mode="teacher")
         res["cpu_baseline"] = cpu_baseline(teacher, ccfg, K, cb)
