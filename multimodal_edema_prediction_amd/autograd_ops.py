@@ -123,6 +123,55 @@ def linear(x, weight, bias=None, residual=None):
     return LinearFn.apply(x, weight, bias, residual)
 
 
+class InProjFn(torch.autograd.Function):
+    """nn.MultiheadAttention's packed input projection as ONE node:  Q = xq W[:d]^T + b[:d],  KV = xkv W[d:]^T + b[d:].
+    Slicing `in_proj_weight` / `in_proj_bias` outside and feeding two Linears makes autograd rebuild the full-size gradients
+    with zero-fill + copy + add kernels (10 launches per block and step); here both weight-gradient GEMMs and both bias sums
+    write straight into their row blocks of one dW [3d, K] / db [3d], and the weight is cast / transposed once."""
+
+    @staticmethod
+    def forward(ctx, xq, xkv, weight, bias, d):
+        K = weight.shape[1]
+        q2 = Fn.to_bf16(xq.contiguous()).reshape(-1, K)
+        kv2 = Fn.to_bf16(xkv.contiguous()).reshape(-1, K)
+        wb = weight_bf16(weight)
+        Q = Fn.gemm(q2, wb[:d], bias=bias[:d], out_dtype=F32, k=K)
+        KV = Fn.gemm(kv2, wb[d:], bias=bias[d:], out_dtype=F32, k=K)
+        ctx.save_for_backward(q2, kv2, weight)
+        ctx.d, ctx.q_shape, ctx.kv_shape = d, xq.shape, xkv.shape
+        return Q.view(*xq.shape[:-1], d), KV.view(*xkv.shape[:-1], weight.shape[0] - d)
+
+    @staticmethod
+    def backward(ctx, dQ, dKV):
+        q2, kv2, weight = ctx.saved_tensors
+        d, (N3, K) = ctx.d, weight.shape
+        dq2 = dQ.reshape(-1, d).contiguous()
+        dkv2 = dKV.reshape(-1, N3 - d).contiguous()
+        dqb, dkvb = Fn.to_bf16(dq2), Fn.to_bf16(dkv2)
+        dxq = dxkv = dw = db = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            wt = weight_t_bf16(weight)                                   # [K, 3d]
+            if ctx.needs_input_grad[0]:
+                dxq = Fn.gemm(dqb, wt[:, :d], out_dtype=F32, k=d).view(ctx.q_shape)
+            if ctx.needs_input_grad[1]:
+                dxkv = Fn.gemm(dkvb, wt[:, d:], out_dtype=F32, k=N3 - d).view(ctx.kv_shape)
+        if ctx.needs_input_grad[2]:
+            dw = torch.empty((N3, K), dtype=F32, device=weight.device)
+            Fn.gemm_tn(dqb, q2, out=dw[:d])
+            Fn.gemm_tn(dkvb, kv2, out=dw[d:])
+        if ctx.needs_input_grad[3]:
+            db = torch.empty(N3, dtype=F32, device=weight.device)
+            Fn.colsum(dq2, out=db[:d])
+            Fn.colsum(dkv2, out=db[d:])
+        return dxq, dxkv, dw, db, None
+
+
+def in_proj(xq, xkv, weight, bias, d):
+    if weight.shape[1] % 8 or d % 8 or (weight.shape[0] - d) % 8 or bias is None:
+        return linear(xq, weight[:d], None if bias is None else bias[:d]), linear(xkv, weight[d:], None if bias is None else bias[d:])
+    return InProjFn.apply(xq, xkv, weight, bias, d)
+
+
 # ---------------------------------------------------------------------------------------------- LayerNorm
 class LayerNormFn(torch.autograd.Function):
     @staticmethod

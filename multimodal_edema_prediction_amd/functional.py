@@ -53,14 +53,17 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, scale=None, residual=None,
     return out
 
 
-def gemm_tn(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """dW[N,K] = dy[M,N]^T @ x[M,K] (bf16 row-major operands, fp32 result) — the weight gradient of a Linear."""
+def gemm_tn(dy: torch.Tensor, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """dW[N,K] = dy[M,N]^T @ x[M,K] (bf16 row-major operands, fp32 result) — the weight gradient of a Linear.
+    `out`: optional contiguous [N, K] fp32 destination (e.g. a row block of a larger gradient)."""
     assert dy.dtype == BF16 and x.dtype == BF16
     dy2, x2 = _2d(dy), _2d(x)
     M, N = dy2.shape
     K = x2.shape[1]
     assert x2.shape[0] == M
-    out = torch.empty((N, K), dtype=F32, device=dy.device)
+    if out is None:
+        out = torch.empty((N, K), dtype=F32, device=dy.device)
+    assert out.shape == (N, K) and out.dtype == F32 and out.is_contiguous()
     wsb = lib().medp_gemm_tn_workspace_bytes(M, N, K)
     ws = torch.empty(wsb // 4, dtype=F32, device=dy.device) if wsb else None
     check(lib().medp_gemm_bf16_tn(ptr(dy2), ptr(x2), ptr(out), M, N, K, _ld(dy2), _ld(x2), ptr(ws), stream()), "gemm_tn")
@@ -91,10 +94,12 @@ def layernorm_bwd(dy, x, w, mean, rstd, need_dx=True, need_dwdb=True):
     return (dx.view(x.shape) if need_dx else None), dw, db
 
 
-def colsum(x: torch.Tensor) -> torch.Tensor:
+def colsum(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
     x2 = _2d(x)
     rows, D = x2.shape
-    out = torch.empty(D, dtype=F32, device=x.device)
+    if out is None:
+        out = torch.empty(D, dtype=F32, device=x.device)
+    assert out.shape == (D,) and out.dtype == F32 and out.is_contiguous()
     ws = torch.empty(lib().medp_colsum_workspace_bytes(rows, D) // 4, dtype=F32, device=x.device)
     check(lib().medp_colsum_f32(ptr(x2), _ld(x2), ptr(out), ptr(ws), rows, D, stream()), "colsum")
     return out

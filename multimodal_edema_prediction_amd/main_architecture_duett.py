@@ -88,9 +88,8 @@ class _PerceiverBlock(nn.Module):
         W, b = self.attn.in_proj_weight, self.attn.in_proj_bias
         q_src = _shared_q if _shared_q is not None else latents
         qn = A.layer_norm(q_src, self.norm_q.weight, self.norm_q.bias, self.norm_q.eps)
-        Q = A.linear(qn, W[:d], b[:d])
         kn = A.layer_norm(kv, self.norm_kv.weight, self.norm_kv.bias, self.norm_kv.eps)
-        KV = A.linear(kn, W[d:], b[d:])
+        Q, KV = A.in_proj(qn, kn, W, b, d)
         o, attn_w = A.attn_small(Q, KV, H, (d // H) ** -0.5, p_attn, seed, self._sid, _kv_skip, return_attn)
         latents = A.linear(o, self.attn.out_proj.weight, self.attn.out_proj.bias, residual=latents)
         h = A.layer_norm(latents, self.norm_ff.weight, self.norm_ff.bias, self.norm_ff.eps)
