@@ -2,6 +2,8 @@
 // HBM-bound: one 64-lane wave per row, float4 loads, wavefront shuffle reductions, statistics in fp32.
 // The row is read from HBM once (the second/third sweep of the same wave hits L1/L2); the output is written
 // as bf16 when it feeds an MFMA GEMM, as fp32 when it is a residual stream.
+#include <stdlib.h>
+
 #include "common.h"
 #include "medp_hip.h"
 
@@ -267,6 +269,40 @@ __global__ __launch_bounds__(256) void sum_all_kernel(const float* __restrict__ 
 
 int colsum_chunks(int rows) { return max(1, min(128, rows / 64)); }
 
+// Few rows (the perceiver's B*7 = 448 latent rows): ONE launch, 64 columns x 16 row-lanes per workgroup, instead of the
+// partial + final pair — these sums sit on the dependent backward chain, where a launch costs more than the arithmetic.
+constexpr int COLSUM_DIRECT_MAX_ROWS = 2048;
+template <int MODE>
+__global__ __launch_bounds__(1024) void colsum_direct_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            float* __restrict__ out_a, float* __restrict__ out_b, int rows, int D) {
+    __shared__ float red[2][16][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float a = 0.f, bsum = 0.f;
+    if (c < D) {
+#pragma unroll 4
+        for (int r = rl; r < rows; r += 16) {
+            const float g = dy[(size_t)r * lddy + c];
+            bsum += g;
+            if (MODE == 1) a += g * (x[(size_t)r * ldx + c] - mean[r]) * rstd[r];
+        }
+    }
+    red[0][rl][cl] = a;
+    red[1][rl][cl] = bsum;
+    __syncthreads();
+    if (rl == 0 && c < D) {
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            sa += red[0][k][cl];
+            sb += red[1][k][cl];
+        }
+        if (MODE == 1 && out_a) out_a[c] = sa;
+        if (out_b) out_b[c] = sb;
+    }
+}
+
 }  // namespace
 
 extern "C" int medp_layernorm_fwd(const float* x, int ldx, const float* w, const float* b, void* y, int ldy, int y_bf16,
@@ -305,6 +341,11 @@ extern "C" int medp_layernorm_bwd(const float* dy, int lddy, const float* x, int
     }
     if (dw || db) {
         MEDP_CHECK_ARG(workspace, "layernorm_bwd: workspace required for dw/db (medp_colsum_workspace_bytes)");
+        if (rows <= COLSUM_DIRECT_MAX_ROWS) {
+            colsum_direct_kernel<1><<<(D + 63) / 64, 1024, 0, s>>>(dy, lddy, x, ldx, mean, rstd, dw, db, rows, D);
+            MEDP_LAUNCH_CHECK("medp_layernorm_bwd(direct)");
+            return 0;
+        }
         const int nchunk = colsum_chunks(rows), rpc = (rows + nchunk - 1) / nchunk;
         colsum_partial_kernel<1><<<dim3((D + 63) / 64, nchunk), 256, 0, s>>>(dy, lddy, x, ldx, mean, rstd, workspace, rows, D, rpc);
         MEDP_LAUNCH_CHECK("medp_layernorm_bwd(partial)");
@@ -317,6 +358,11 @@ extern "C" int medp_layernorm_bwd(const float* dy, int lddy, const float* x, int
 extern "C" int medp_colsum_f32(const float* x, int ldx, float* out, float* workspace, int rows, int D, void* stream) {
     MEDP_CHECK_ARG(x && out && workspace && rows > 0 && D > 0, "colsum: bad argument");
     hipStream_t s = (hipStream_t)stream;
+    if (rows <= COLSUM_DIRECT_MAX_ROWS) {
+        colsum_direct_kernel<0><<<(D + 63) / 64, 1024, 0, s>>>(x, ldx, nullptr, 0, nullptr, nullptr, nullptr, out, rows, D);
+        MEDP_LAUNCH_CHECK("medp_colsum_f32(direct)");
+        return 0;
+    }
     const int nchunk = colsum_chunks(rows), rpc = (rows + nchunk - 1) / nchunk;
     colsum_partial_kernel<0><<<dim3((D + 63) / 64, nchunk), 256, 0, s>>>(x, ldx, nullptr, 0, nullptr, nullptr, workspace, rows, D, rpc);
     MEDP_LAUNCH_CHECK("medp_colsum_f32(partial)");
