@@ -153,7 +153,10 @@ class Dinov2Backbone(nn.Module):
             raise ValueError("Make sure that the channel dimension of the pixel values match with the one set in the "
                              f"configuration. Expected {self.cfg.num_channels} but got {tuple(pixel_values.shape)}.")
         if any(p.requires_grad for p in self.parameters()) and torch.is_grad_enabled():
-            raise NotImplementedError("ViT backward (--unfreeze_cxr) is not built yet (SURVEY.md §8f-1); keep the CXR encoder frozen")
+            # --unfreeze_cxr: the forward is composed of autograd nodes over the same kernels (cxr_train.py)
+            from .cxr_train import forward_training
+            tok = forward_training(self, pixel_values)
+            return (tok if want_f32 else None), (tok if want_bf16 else None)       # fp32 either way: it carries the gradient
         w, _, _ = self._prepare()
         px = pixel_values.detach().to(torch.float32).contiguous()
         B, _, H, W = px.shape
@@ -212,6 +215,7 @@ class CXREncoder(nn.Module):
         return cls
 
     def forward_bf16(self, pixel_values: torch.Tensor):
-        """Build-internal fast path: tokens as bf16 [B, P+1, D], directly consumable by the img_proj GEMM."""
+        """Build-internal fast path: tokens as bf16 [B, P+1, D], directly consumable by the img_proj GEMM (fp32 tokens with a
+        gradient when the encoder is being trained)."""
         _, t16 = self.backbone(pixel_values, want_f32=False, want_bf16=True)
         return t16

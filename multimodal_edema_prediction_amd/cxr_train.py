@@ -1,0 +1,114 @@
+"""Trainable form of the CXR encoder (`--unfreeze_cxr`, run.py:184-187; SURVEY.md §8(f1), second half).
+
+The frozen encoder is one C call (`medp_vit_forward`); when any of its parameters requires a gradient the forward is
+composed here from the autograd nodes of `autograd_ops` instead — the same HIP kernels (bf16 MFMA GEMMs incl. the transposed
+weight-gradient GEMM, LayerNorm forward/backward, flash attention forward) plus two nodes of its own:
+
+* `PatchEmbedFn`: conv14/stride14 as im2col + GEMM; backward is the weight-gradient GEMM on the saved bf16 columns;
+* `AttnDh64Fn`: forward = the head-dim-64 MFMA kernel; backward = the fp32 small-attention backward kernel (probabilities
+  recomputed from the saved fp32 q / k / v) — CORRECT BUT NOT TUNED: it is the latency-oriented kernel of the perceiver
+  blocks run at 257 x 257, roughly 100x off an MFMA flash backward.  Building that kernel is the open part of §8(f1).
+
+LayerScale and the residual adds are plain torch elementwise ops here (plumbing, autograd included).
+Parity: tests/test_gpu_unfrozen_cxr.py against the oracle's autograd.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import autograd_ops as A
+from . import functional as Fn
+from .abi import check, lib, ptr, stream
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+class PatchEmbedFn(torch.autograd.Function):
+    """pixels [B,3,H,W] fp32, weight [D,3,p,p], bias [D] -> patch tokens [B, P, D] fp32."""
+
+    @staticmethod
+    def forward(ctx, pixels, weight, bias, patch):
+        B, C, H, W = pixels.shape
+        gh, gw = H // patch, W // patch
+        D, K = weight.shape[0], C * patch * patch
+        kpad = (K + 7) // 8 * 8
+        cols = torch.empty((B * gh * gw, kpad), dtype=BF16, device=pixels.device)
+        px = pixels.detach().to(F32).contiguous()
+        check(lib().medp_im2col_patch(ptr(px), ptr(cols), B, C, H, W, patch, kpad, stream()), "im2col_patch")
+        wpad = torch.zeros((D, kpad), dtype=F32, device=pixels.device)
+        wpad[:, :K] = weight.detach().reshape(D, K)
+        y = Fn.gemm(cols, Fn.to_bf16(wpad), bias=bias.detach(), out_dtype=F32, k=kpad)
+        ctx.save_for_backward(cols)
+        ctx.wshape, ctx.K = weight.shape, K
+        return y.view(B, gh * gw, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (cols,) = ctx.saved_tensors
+        D = ctx.wshape[0]
+        dy2 = dy.reshape(-1, D).contiguous()
+        dw = Fn.gemm_tn(Fn.to_bf16(dy2), cols)[:, :ctx.K].reshape(ctx.wshape)
+        return None, dw, Fn.colsum(dy2), None
+
+
+class AttnDh64Fn(torch.autograd.Function):
+    """qkv fp32 [B*S, 3*H*64] (q | k | v column blocks) -> o fp32 [B*S, H*64]."""
+
+    @staticmethod
+    def forward(ctx, qkv, B, S, H):
+        o = Fn.attn_dh64(Fn.to_bf16(qkv.contiguous()), B, S, H, 0.125)
+        ctx.save_for_backward(qkv)
+        ctx.dims = (B, S, H)
+        return o.float()
+
+    @staticmethod
+    def backward(ctx, do):
+        (qkv,) = ctx.saved_tensors
+        B, S, H = ctx.dims
+        D = H * 64
+        q3 = qkv.view(B, S, 3 * D)
+        q, k, v = q3[..., :D], q3[..., D:2 * D], q3[..., 2 * D:]
+        dq, dk, dv = Fn.attn_small_bwd(do.contiguous().view(B, S, D), q, k, v, B, S, S, H, 64, 0.125,
+                                       q_batch_stride=S * 3 * D, kv_batch_stride=S * 3 * D)
+        return torch.cat([dq, dk, dv], dim=-1).view(B * S, 3 * D), None, None, None
+
+
+def forward_training(backbone, pixel_values: torch.Tensor) -> torch.Tensor:
+    """Dinov2Model.forward(...).last_hidden_state with autograd through every parameter: [B, P+1, hidden] fp32."""
+    c = backbone.cfg
+    sd = dict(backbone.named_parameters())
+    B, _, Hh, Ww = pixel_values.shape
+    D, H = c.hidden_size, c.num_attention_heads
+    if D != H * 64:
+        raise ValueError("the attention kernel needs head dim 64")
+    gh, gw = Hh // c.patch_size, Ww // c.patch_size
+    patch = PatchEmbedFn.apply(pixel_values, sd["embeddings.patch_embeddings.projection.weight"],
+                               sd["embeddings.patch_embeddings.projection.bias"], c.patch_size)
+    cls = sd["embeddings.cls_token"].reshape(1, 1, D).expand(B, 1, D)
+    pos = sd["embeddings.position_embeddings"].reshape(1, -1, D)
+    side = c.image_size // c.patch_size
+    if not (gh == side and gw == side):
+        # modeling_dinov2.py:57-95: bicubic resize of the stored patch grid (align_corners=False).  The frozen path has its own
+        # kernel for this (medp_pos_embed_bicubic); the trainable path needs the transpose as well and takes torch's
+        # interpolate with its autograd — 257 x 768 values once per step, plumbing next to the encoder's 92 GFLOP/sample backward
+        grid = pos[:, 1:].reshape(1, side, side, D).permute(0, 3, 1, 2)
+        grid = torch.nn.functional.interpolate(grid, size=(gh, gw), mode="bicubic", align_corners=False)
+        pos = torch.cat([pos[:, :1], grid.permute(0, 2, 3, 1).reshape(1, gh * gw, D)], dim=1)
+    x = torch.cat([cls, patch], dim=1) + pos
+    S = x.shape[1]
+    x = x.reshape(B * S, D)
+    for l in range(c.num_hidden_layers):
+        p = f"encoder.layer.{l}."
+        h = A.layer_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], c.layer_norm_eps)
+        wqkv = torch.cat([sd[p + f"attention.attention.{n}.weight"] for n in ("query", "key", "value")], 0)
+        bqkv = torch.cat([sd[p + f"attention.attention.{n}.bias"] for n in ("query", "key", "value")], 0)
+        qkv = A.linear(h, wqkv, bqkv)
+        att = AttnDh64Fn.apply(qkv, B, S, H)
+        y = A.linear(att, sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"])
+        x = x + y * sd[p + "layer_scale1.lambda1"]
+        h = A.layer_norm(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"], c.layer_norm_eps)
+        f = A.gelu_dropout(A.linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]), 0.0, 0, 0)
+        y = A.linear(f, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+        x = x + y * sd[p + "layer_scale2.lambda1"]
+    x = A.layer_norm(x, sd["layernorm.weight"], sd["layernorm.bias"], c.layer_norm_eps)
+    return x.view(B, S, D)
