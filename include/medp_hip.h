@@ -55,6 +55,16 @@ int medp_gemm_profile_collect(double* host_total_ms, long long* host_n_launches,
  * q/k/v: [B*S, ...] rows with strides ld*, head h at column h*64.  o: [B*S, H*64]. */
 int medp_attn_fwd_dh64(const void* q, const void* k, const void* v, void* o, int B, int S, int H, int ldq, int ldk,
                        int ldv, int ldo, float scale, void* stream);
+/* Training form (--unfreeze_cxr, run.py:184-187): the same forward that also writes lse[B,H,S], the log2-domain logsumexp of the
+ * scaled scores, and the flash backward that consumes it.  prep: dsum[b,h,s] = <dout, o> and the bf16 copy of dout.
+ * bwd: dq/dk/dv fp32 with row stride ldd (e.g. the three column blocks of one [B*S, 3*H*64] buffer); q/k/v/dout_bf16 bf16. */
+int medp_attn_fwd_dh64_lse(const void* q, const void* k, const void* v, void* o, float* lse, int B, int S, int H, int ldq,
+                           int ldk, int ldv, int ldo, float scale, void* stream);
+int medp_attn_bwd_dh64_prep(const float* dout, int lddout, const void* o_bf16, int ldo, void* dout_bf16, int lddob,
+                            float* dsum, int B, int S, int H, void* stream);
+int medp_attn_bwd_dh64(const void* q, const void* k, const void* v, int ldqkv, const void* dout_bf16, int lddo,
+                       const float* lse, const float* dsum, float* dq, float* dk, float* dv, int ldd, int B, int S, int H,
+                       float scale, void* stream);
 /* Small fp32 attention (head dim <= 64, Lk <= 1536), fwd/bwd with optional dropout on the probabilities and
  * optional head-averaged weights (pre-zeroed [B,Lq,Lk]): x_transformers Attention inside the DuETT encoders
  * (model :81,:91) and nn.MultiheadAttention inside _PerceiverBlock (model :759-762, need_weights/average). */

@@ -60,6 +60,9 @@ SIGNATURES = {
     "medp_gemm_profile_enable": (I, [I]),
     "medp_gemm_profile_collect": (I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_longlong), ctypes.POINTER(ctypes.c_double)]),
     "medp_attn_fwd_dh64": (I, [P, P, P, P, I, I, I, I, I, I, I, F, P]),
+    "medp_attn_fwd_dh64_lse": (I, [P, P, P, P, P, I, I, I, I, I, I, I, F, P]),
+    "medp_attn_bwd_dh64_prep": (I, [P, I, P, I, P, I, P, I, I, I, P]),
+    "medp_attn_bwd_dh64": (I, [P, P, P, I, P, I, P, P, P, P, P, I, I, I, I, F, P]),
     "medp_attn_small_fwd": (I, [P, I, LL, P, P, I, LL, P, I, I, P, I, I, I, I, I, F, F, U, U, P]),
     "medp_attn_small_bwd": (I, [P, I, P, I, LL, P, P, I, LL, P, I, P, I, P, I, LL, I, I, I, I, I, F, F, U, U, P]),
     "medp_layernorm_fwd": (I, [P, I, P, P, P, I, I, P, P, I, I, F, P]),

@@ -34,6 +34,7 @@ struct AttnParams {
     int ldq, ldk, ldv, ldo;
     float scale_log2e;
     int crows;   // LDS rows per K / V image
+    float* lse;  // optional [B, H, S]: log2-domain logsumexp of the scaled scores (training: consumed by the backward)
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
@@ -218,6 +219,7 @@ __device__ __forceinline__ void wave_body(const AttnParams& p, char* sK, char* s
             l += __shfl_xor(l, 32, 64);
             const float inv = 1.0f / l;
             const int qi = q0 + qs * 16 + fr;
+            if (p.lse && kq == 0 && qi < p.S) p.lse[((size_t)b * p.H + h) * p.S + qi] = w.m_run[qs] * p.scale_log2e + __log2f(l);
             if (qi < p.S) {
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
@@ -250,15 +252,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dh64_kernel(const AttnParams 
 
 }  // namespace
 
-extern "C" int medp_attn_fwd_dh64(const void* q, const void* k, const void* v, void* o, int B, int S, int H, int ldq,
-                                  int ldk, int ldv, int ldo, float scale, void* stream) {
+static int attn_fwd_launch(const void* q, const void* k, const void* v, void* o, float* lse, int B, int S, int H, int ldq, int ldk,
+                           int ldv, int ldo, float scale, void* stream) {
     MEDP_CHECK_ARG(q && k && v && o, "attn_fwd_dh64: null operand");
     MEDP_CHECK_ARG(B > 0 && S > 0 && H > 0, "attn_fwd_dh64: bad shape B=%d S=%d H=%d", B, S, H);
     MEDP_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "attn_fwd_dh64: row strides must keep 16-B alignment");
     MEDP_CHECK_ARG(B <= 65535 && H <= 65535, "attn_fwd_dh64: grid limit");
     MEDP_CHECK_ARG(scale > 0.f, "attn_fwd_dh64: scale must be positive (it is folded into the running max)");
     AttnParams p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, B, S, H, ldq, ldk, ldv, ldo,
-                 scale * 1.4426950408889634f, 0};
+                 scale * 1.4426950408889634f, 0, lse};
     p.crows = min(KC, (S + 31) / 32 * 32);
     constexpr int LDS_MAX = 2 * KC * 128;
     const int LDS = 2 * p.crows * 128;
@@ -273,4 +275,15 @@ extern "C" int medp_attn_fwd_dh64(const void* q, const void* k, const void* v, v
     attn_fwd_dh64_kernel<<<grid, 256, LDS, (hipStream_t)stream>>>(p);
     MEDP_LAUNCH_CHECK("medp_attn_fwd_dh64");
     return 0;
+}
+
+extern "C" int medp_attn_fwd_dh64(const void* q, const void* k, const void* v, void* o, int B, int S, int H, int ldq,
+                                  int ldk, int ldv, int ldo, float scale, void* stream) {
+    return attn_fwd_launch(q, k, v, o, nullptr, B, S, H, ldq, ldk, ldv, ldo, scale, stream);
+}
+
+extern "C" int medp_attn_fwd_dh64_lse(const void* q, const void* k, const void* v, void* o, float* lse, int B, int S, int H,
+                                      int ldq, int ldk, int ldv, int ldo, float scale, void* stream) {
+    MEDP_CHECK_ARG(lse, "attn_fwd_dh64_lse: null lse");
+    return attn_fwd_launch(q, k, v, o, lse, B, S, H, ldq, ldk, ldv, ldo, scale, stream);
 }

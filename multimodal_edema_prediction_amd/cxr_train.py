@@ -5,9 +5,8 @@ composed here from the autograd nodes of `autograd_ops` instead — the same HIP
 weight-gradient GEMM, LayerNorm forward/backward, flash attention forward) plus two nodes of its own:
 
 * `PatchEmbedFn`: conv14/stride14 as im2col + GEMM; backward is the weight-gradient GEMM on the saved bf16 columns;
-* `AttnDh64Fn`: forward = the head-dim-64 MFMA kernel; backward = the fp32 small-attention backward kernel (probabilities
-  recomputed from the saved fp32 q / k / v) — CORRECT BUT NOT TUNED: it is the latency-oriented kernel of the perceiver
-  blocks run at 257 x 257, roughly 100x off an MFMA flash backward.  Building that kernel is the open part of §8(f1).
+* `AttnDh64Fn`: forward = the head-dim-64 MFMA kernel (also writing the logsumexp); backward = the MFMA flash backward of
+  attention_dh64_bwd.hip (dQ and dK/dV launches of one templated kernel).
 
 LayerScale and the residual adds are plain torch elementwise ops here (plumbing, autograd included).
 Parity: tests/test_gpu_unfrozen_cxr.py against the oracle's autograd.
@@ -21,6 +20,7 @@ from . import functional as Fn
 from .abi import check, lib, ptr, stream
 
 BF16, F32 = torch.bfloat16, torch.float32
+_SMALL_BWD = __import__("os").environ.get("MEDP_ATTN_BWD", "") == "small"
 
 
 class PatchEmbedFn(torch.autograd.Function):
@@ -52,25 +52,30 @@ class PatchEmbedFn(torch.autograd.Function):
 
 
 class AttnDh64Fn(torch.autograd.Function):
-    """qkv fp32 [B*S, 3*H*64] (q | k | v column blocks) -> o fp32 [B*S, H*64]."""
+    """qkv fp32 [B*S, 3*H*64] (q | k | v column blocks) -> o fp32 [B*S, H*64].  Forward and backward are the head-dim-64 MFMA
+    flash kernels (attention_dh64.hip / attention_dh64_bwd.hip); `MEDP_ATTN_BWD=small` selects the fp32 small-attention
+    backward instead (the first, slow implementation — kept as a cross-check)."""
 
     @staticmethod
     def forward(ctx, qkv, B, S, H):
-        o = Fn.attn_dh64(Fn.to_bf16(qkv.contiguous()), B, S, H, 0.125)
-        ctx.save_for_backward(qkv)
+        qkv16 = Fn.to_bf16(qkv.contiguous())
+        o, lse = Fn.attn_dh64_lse(qkv16, B, S, H, 0.125)
+        ctx.save_for_backward(qkv, qkv16, o, lse)
         ctx.dims = (B, S, H)
         return o.float()
 
     @staticmethod
     def backward(ctx, do):
-        (qkv,) = ctx.saved_tensors
+        qkv, qkv16, o, lse = ctx.saved_tensors
         B, S, H = ctx.dims
         D = H * 64
-        q3 = qkv.view(B, S, 3 * D)
-        q, k, v = q3[..., :D], q3[..., D:2 * D], q3[..., 2 * D:]
-        dq, dk, dv = Fn.attn_small_bwd(do.contiguous().view(B, S, D), q, k, v, B, S, S, H, 64, 0.125,
-                                       q_batch_stride=S * 3 * D, kv_batch_stride=S * 3 * D)
-        return torch.cat([dq, dk, dv], dim=-1).view(B * S, 3 * D), None, None, None
+        if _SMALL_BWD:
+            q3 = qkv.view(B, S, 3 * D)
+            q, k, v = q3[..., :D], q3[..., D:2 * D], q3[..., 2 * D:]
+            dq, dk, dv = Fn.attn_small_bwd(do.contiguous().view(B, S, D), q, k, v, B, S, S, H, 64, 0.125,
+                                           q_batch_stride=S * 3 * D, kv_batch_stride=S * 3 * D)
+            return torch.cat([dq, dk, dv], dim=-1).view(B * S, 3 * D), None, None, None
+        return Fn.attn_dh64_bwd(do, qkv16, o, lse, B, S, H, 0.125), None, None, None
 
 
 def forward_training(backbone, pixel_values: torch.Tensor) -> torch.Tensor:

@@ -138,6 +138,32 @@ def attn_dh64(qkv: torch.Tensor, B: int, S: int, H: int, scale: float) -> torch.
     return o
 
 
+def attn_dh64_lse(qkv: torch.Tensor, B: int, S: int, H: int, scale: float):
+    """Training form of `attn_dh64`: also returns lse fp32 [B, H, S] (log2-domain logsumexp of the scaled scores)."""
+    assert qkv.dtype == BF16 and qkv.dim() == 2 and qkv.shape == (B * S, 3 * H * 64)
+    D = H * 64
+    o = torch.empty((B * S, D), dtype=BF16, device=qkv.device)
+    lse = torch.empty((B, H, S), dtype=F32, device=qkv.device)
+    base = qkv.data_ptr()
+    check(lib().medp_attn_fwd_dh64_lse(base, base + 2 * D, base + 4 * D, ptr(o), ptr(lse), B, S, H, 3 * D, 3 * D, 3 * D, D, scale,
+                                       stream()), "attn_fwd_dh64_lse")
+    return o, lse
+
+
+def attn_dh64_bwd(dout: torch.Tensor, qkv: torch.Tensor, o: torch.Tensor, lse: torch.Tensor, B: int, S: int, H: int, scale: float):
+    """dout fp32 [B*S, H*64], qkv / o bf16 as in the forward -> dqkv fp32 [B*S, 3*H*64] (dq | dk | dv column blocks)."""
+    D = H * 64
+    d2 = dout.reshape(B * S, D).contiguous()
+    dob = torch.empty((B * S, D), dtype=BF16, device=qkv.device)
+    dsum = torch.empty((B, H, S), dtype=F32, device=qkv.device)
+    check(lib().medp_attn_bwd_dh64_prep(ptr(d2), D, ptr(o), D, ptr(dob), D, ptr(dsum), B, S, H, stream()), "attn_bwd_dh64_prep")
+    dqkv = torch.empty((B * S, 3 * D), dtype=F32, device=qkv.device)
+    base, dbase = qkv.data_ptr(), dqkv.data_ptr()
+    check(lib().medp_attn_bwd_dh64(base, base + 2 * D, base + 4 * D, 3 * D, ptr(dob), D, ptr(lse), ptr(dsum), dbase, dbase + 4 * D,
+                                   dbase + 8 * D, 3 * D, B, S, H, scale, stream()), "attn_bwd_dh64")
+    return dqkv
+
+
 def attn_small_fwd(q, k, v, B, Lq, Lk, H, dh, scale, *, q_batch_stride=None, kv_batch_stride=None, out_dtype=F32,
                    dropout_p=0.0, seed=0, stream_id=0, attn_avg=None):
     """q fp32 rows [.., H*dh] (ld = q.stride(-2)); k, v fp32 with a common row stride."""
