@@ -28,12 +28,12 @@ PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, /opt/skills/guides/MI
 GFLOP_PER_SAMPLE = 48.25           # ViT 46.32 + DuETT fwd 1.04 + 3 x fusion 0.294
 
 
-def build_teacher(T, V, DS, K, device, seed=0):
+def build_teacher(T, V, DS, K, device, seed=0, freeze_cxr=True):
     from multimodal_edema_prediction_amd.main_architecture_duett import (CXREncoder, PatchDualPathologyPerceiver, TeacherModel,
                                                                            load_duett_backbone)
     torch.manual_seed(seed)
     backbone = load_duett_backbone("synthetic", d_static_num=DS, d_time_series_num=V, n_timesteps=T, freeze=True)   # --freeze_duett
-    cxr = CXREncoder("synthetic", freeze=True, return_patches=True)
+    cxr = CXREncoder("synthetic", freeze=freeze_cxr, return_patches=True)
     perceiver = PatchDualPathologyPerceiver(n_pathologies=K, d_ts=backbone.d_representation, d_latent=256, n_heads=4, dropout=0.2)
     teacher = TeacherModel(backbone, cxr, perceiver, head_hidden=128, head_dropout=0.2, cxr_return_patches=True, d_img=cxr.d_out,
                            use_aux_cxr=False, patch_dual_pathology_mode=True)
@@ -89,6 +89,8 @@ def main():
                     help="graph mode: run the frozen CXR encoder inside its own batch's step instead of one batch ahead")
     ap.add_argument("--host-batch", action="store_true", help="keep batches on the host: PCIe-inclusive rate (never `value`)")
     ap.add_argument("--eager", action="store_true", help="run the step eagerly from Python (engine.py) instead of replaying the captured HIP graph")
+    ap.add_argument("--unfreeze-cxr", action="store_true",
+                    help="train the CXR encoder too (run.py --unfreeze_cxr; SURVEY 8f1): a side measurement, never the contract line")
     ap.add_argument("--stress", action="store_true",
                     help="BASELINE.json configs[4] shapes per GPU (CXR 512x512, T=256, F=96, batch 32 = 256 / 8 GPUs) instead of the "
                          "metric's configs[2]; a side measurement, never the contract line")
@@ -117,7 +119,7 @@ def main():
         T, V, img = 256, 96, 512
         B = 32 if args.batch == 64 else args.batch
     ccfg = CohortCfg(n_timesteps=T, n_vars=V, d_static=DS, image_size=img, n_labels=K, seed=1234)
-    teacher = build_teacher(T, V, DS, K, device)
+    teacher = build_teacher(T, V, DS, K, device, freeze_cxr=not args.unfreeze_cxr)
     dp.broadcast_parameters(teacher)
     loss_fn = DualPathologyLoss(torch.ones(K), None, 0.5, 0.5, 1.0).to(device)
     opt = FusedAdamW(make_param_groups(teacher, 8e-5), weight_decay=5e-2)
@@ -144,7 +146,7 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
             torch.distributed.init_process_group("nccl", rank=0, world_size=1)
         gstep = GraphedTeacherStep(teacher, loss_fn, opt, pool[0], device, world=2 if force_pg else world,
-                                   pipeline_cxr=not args.no_pipeline)
+                                   pipeline_cxr=not (args.no_pipeline or args.unfreeze_cxr))
         if force_pg:
             gstep.world = 1
             _ar = gstep._allreduce
@@ -207,14 +209,16 @@ def main():
         "metric": "multimodal train samples/sec", "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": ("BASELINE.json configs[4] shapes (STRESS side measurement, not the metric's configuration): full multimodal "
+        "config": {"workload": ("SIDE MEASUREMENT (--unfreeze_cxr, SURVEY 8f1): configs[2] shapes with the CXR encoder TRAINED as well, "
+                                f"batch {B} per GPU, captured graph, no encoder pipelining" if args.unfreeze_cxr else
+                                "BASELINE.json configs[4] shapes (STRESS side measurement, not the metric's configuration): full multimodal "
                                 f"teacher, CXR {img}x{img} ViT-B/14 + DuETT T={T}/F={V}, batch {B} per GPU" if args.stress else
                                 "BASELINE.json configs[2]: full multimodal teacher (main_train_teacher_duett, perceiver_type=dual_patch, "
                                 "--freeze_duett, frozen CXR): CXR 224x224 ViT-B/14 + DuETT T=96/F=48, batch 64 per GPU, bf16 MFMA / fp32 "
                                 "accumulate, random-init weights, synthetic cohort seed 1234, perceiver dropout 0.2 ON"),
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                   "gflop_per_sample": None if args.stress else GFLOP_PER_SAMPLE,
-                   "step_mfma_fraction_of_peak": None if args.stress else round(value * GFLOP_PER_SAMPLE / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
+                   "gflop_per_sample": None if (args.stress or args.unfreeze_cxr) else GFLOP_PER_SAMPLE,
+                   "step_mfma_fraction_of_peak": None if (args.stress or args.unfreeze_cxr) else round(value * GFLOP_PER_SAMPLE / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
                    "last_loss": round(float(last["loss"]), 5), "batch_location": "host" if args.host_batch else "hbm",
                    "execution": "eager (engine.py from Python)" if args.eager else (
                        "captured HIP graph replay (graph_step.py), two-stream step" if args.no_pipeline else
@@ -226,7 +230,7 @@ def main():
                      "avg_launch_us": round(ms.value * 1e3 / max(n_l.value, 1), 2),
                      "algorithmic_flops_per_launch": round(fl.value / max(n_l.value, 1), 1)},
     }
-    if world == 1 and not args.no_cpu_baseline and not args.stress:
+    if world == 1 and not args.no_cpu_baseline and not args.stress and not args.unfreeze_cxr:
         nb = 4
         cb = make_batch(ccfg, start=10_000, batch_size=nb, mode="teacher")
         res["cpu_baseline"] = cpu_baseline(teacher, ccfg, K, cb)
