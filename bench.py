@@ -152,10 +152,25 @@ def main():
             _ar = gstep._allreduce
             gstep._allreduce = lambda: torch.distributed.all_reduce(gstep.flat_grad, op=torch.distributed.ReduceOp.AVG)
 
+        # One host read of the loss per step, like the reference's per-step logging — of the PREVIOUS step: the loss is copied
+        # to pinned memory behind an event, so the host enqueues replay k+1 while the GPU still runs replay k instead of
+        # idling the GPU for a launch latency every step (0.14 ms of 5.7).  Every step still runs to completion inside the
+        # timed region (the final torch.cuda.synchronize()).
+        _pin = [torch.empty((), dtype=torch.float32, pin_memory=True) for _ in range(2)]
+        _ev = [torch.cuda.Event() for _ in range(2)]
+        _state = {"n": 0, "loss": float("nan")}
+
         def step(i):
             out = gstep.step(pool[i % n_pool], pool[(i + 1) % n_pool])     # (batch to train on, batch the next call will bring)
             sched.step()
-            return {"loss": out["loss"].item()}          # one host read per step, like the reference's per-step logging
+            k = _state["n"]
+            _pin[k % 2].copy_(out["loss"], non_blocking=True)
+            _ev[k % 2].record()
+            if k > 0:
+                _ev[(k - 1) % 2].synchronize()
+                _state["loss"] = float(_pin[(k - 1) % 2])
+            _state["n"] = k + 1
+            return {"loss": _state["loss"]}
 
     import warnings
     warnings.filterwarnings("ignore", message=".*lr_scheduler.step.*")
@@ -175,6 +190,8 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
+    if not args.eager:
+        last = {"loss": float(gstep.out["loss"].item())}          # the final step's loss (steps report the previous one)
     if not args.eager:
         # Graph replay: HIP events cannot be read back out of a replayed hipGraph on this ROCm (hipEventElapsedTime ->
         # "invalid resource handle"), so the dominant kernel is timed right after the timed region, same process, same
