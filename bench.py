@@ -145,6 +145,11 @@ def main():
         if force_pg and not torch.distributed.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
             torch.distributed.init_process_group("nccl", rank=0, world_size=1)
+        if not args.host_batch:       # resident batches: stack the per-sample tuples once instead of on every step
+            pool_g = [dict(b, x_ts=torch.stack(tuple(b["x_ts"])), x_static=torch.stack(tuple(b["x_static"])),
+                           bin_ends=torch.stack(tuple(b["bin_ends"]))) for b in pool]
+        else:
+            pool_g = pool
         gstep = GraphedTeacherStep(teacher, loss_fn, opt, pool[0], device, world=2 if force_pg else world,
                                    pipeline_cxr=not (args.no_pipeline or args.unfreeze_cxr))
         if force_pg:
@@ -161,7 +166,7 @@ def main():
         _state = {"n": 0, "loss": float("nan")}
 
         def step(i):
-            out = gstep.step(pool[i % n_pool], pool[(i + 1) % n_pool])     # (batch to train on, batch the next call will bring)
+            out = gstep.step(pool_g[i % n_pool], pool_g[(i + 1) % n_pool])     # (batch to train on, batch the next call will bring)
             sched.step()
             k = _state["n"]
             _pin[k % 2].copy_(out["loss"], non_blocking=True)

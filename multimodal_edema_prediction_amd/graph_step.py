@@ -139,9 +139,11 @@ class GraphedTeacherStep:
 
     def load_batch(self, batch: dict) -> None:
         """Copy a batch (host or device) into the static input buffers (async on the current stream)."""
-        self.x_ts.copy_(torch.stack(tuple(batch["x_ts"])), non_blocking=True)
-        self.x_static.copy_(torch.stack(tuple(batch["x_static"])), non_blocking=True)
-        self.bin_ends.copy_(torch.stack(tuple(batch["bin_ends"])), non_blocking=True)
+        def stacked(v):           # the collate layout is tuples of per-sample tensors; an already stacked tensor is taken as is
+            return v if torch.is_tensor(v) else torch.stack(tuple(v))
+        self.x_ts.copy_(stacked(batch["x_ts"]), non_blocking=True)
+        self.x_static.copy_(stacked(batch["x_static"]), non_blocking=True)
+        self.bin_ends.copy_(stacked(batch["bin_ends"]), non_blocking=True)
         if not self.pipeline:                        # pipelined: this batch's pixels were consumed by the previous replay
             self.pixels.copy_(batch["pixel_values"], non_blocking=True)
         self.y_multi.copy_(batch["y_multi"], non_blocking=True)
