@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_uint, c_voi
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmedp_hip.so")
+LIB_PATH = os.environ.get("MEDP_HIP_LIB") or os.path.join(_HERE, "libmedp_hip.so")   # override: the -DMEDP_V7_PHASE_TRACE profiling build
 
 P, I, F, U, LL, SZ = c_void_p, c_int, c_float, c_uint, c_longlong, c_size_t
 

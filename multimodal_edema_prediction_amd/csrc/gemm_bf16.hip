@@ -540,7 +540,17 @@ int medp_gemm_bf16_nt_tagged(int tag, const void* A, const void* W, void* C, int
     // 256^2 tiles to occupy most of the chip (the CXR-encoder shapes: 195 / 585 / 780 tiles); v3 keeps the smaller grids
     const int tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
     const bool use_v6 = M >= 2048 && N >= 256 && (force == 6 || (force == 0 && tiles256 >= 160));
-    if (use_v6 && tag != 1) return medp_gemm_v6_launch(a4, 0, stream);
+    // v7: the same K-loop, persistent over the tile list, where the grid is more than one round of workgroups (qkv, fc1)
+    static const int v7_on = [] { const char* e = getenv("MEDP_GEMM_V7"); return e ? atoi(e) : 1; }();
+    const bool use_v7 = use_v6 && force != 6 && v7_on && medp_gemm_v7_eligible(a4);
+    auto launch_v67 = [&](int tg) {
+        if (use_v7) {
+            const int rc = medp_gemm_v7_launch(a4, tg, stream);
+            if (rc != -1) return rc;
+        }
+        return medp_gemm_v6_launch(a4, tg, stream);
+    };
+    if (use_v6 && tag != 1) return launch_v67(0);
     if (use_v5 && tag != 1) return medp_gemm_v5_launch(a4, 0, stream);
     if (use_v4 && tag != 1 && M >= 2048 && N >= 256) return medp_gemm_v4_launch(a4, 0, stream);
     if (use_v3 && tag != 1) return launch_v3<0>(p, s);
@@ -557,7 +567,7 @@ int medp_gemm_bf16_nt_tagged(int tag, const void* A, const void* W, void* C, int
             }
             hipEventRecord(g_prof.ev[g_prof.used], s);
         }
-        const int rc = use_v6 ? medp_gemm_v6_launch(a4, 1, stream) : use_v5 ? medp_gemm_v5_launch(a4, 1, stream) : use_v4 ? medp_gemm_v4_launch(a4, 1, stream)
+        const int rc = use_v6 ? launch_v67(1) : use_v5 ? medp_gemm_v5_launch(a4, 1, stream) : use_v4 ? medp_gemm_v4_launch(a4, 1, stream)
                               : (use_v3 ? launch_v3<1>(p, s) : (use_v2 ? launch_v2<1>(p, s) : launch<128, 128, 1>(p, s)));
         if (prof) {
             hipEventRecord(g_prof.ev[g_prof.used + 1], s);

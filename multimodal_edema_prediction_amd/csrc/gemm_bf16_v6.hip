@@ -12,10 +12,20 @@
 // W rows 128-255), 128-B rows, 16-B chunk c stored at c ^ (row & 7) (conflict-free ds_read_b128 lane groups).
 // Fragment schedule of K-tile t (per wave): P1 reads A0 (8) + W0 (4), P2 W1 (4), P3 A1 (8), P4 nothing;
 // MFMA quadrants: P1 (A0,W0)  P2 (A0,W1)  P3 (A1,W1)  P4 (A1,W0).
-// LDS-DMA stream, one half-tile (2 pieces per lane) per phase, each into a region whose last read ended >= 1 phase ago:
-//     P1(t): A-lo(t+1)   P2(t): A-hi(t+1)   P3(t): W-lo(t+2)   P4(t): W-hi(t+2), then vmcnt(4) -> K-tile t+1 landed.
-// RAW: the retiring wait sits in P4(t)'s load section (before a barrier every wave passes); K-tile t+1 is first read in
-// P1(t+1), one phase later.  WAR: every ds_read is retired (lgkmcnt(0)) before the barrier that ends its load section.
+// Phase plan of K-tile t (per wave; in-kernel phase clocks, tools/trace_gemm_v7.py --phases, decided it: a load section with
+// 12 ds_read_b128 took 670 ticks against ~330 for the 16 MFMAs it has to hide behind, one with 8 or 4 reads 300-360):
+//     P1: read A rows 0-63 (8)                            MFMA (A0, W0)
+//     P2: read W1 (4),            DMA A rows 0-63 (t+2)   MFMA (A0, W1)      wait vmcnt(10): A rows 64-127 of K-tile t
+//     P3: read A rows 64-127 (8), DMA W half 0 (t+2)      MFMA (A1, W1)      wait vmcnt(6):  W of K-tile t+1
+//     P4: read W0 of K-TILE t+1 (4) into the other W0 register set,
+//                                 DMA W half 1, A rows 64-127 (t+2)          MFMA (A1, W0)
+// i.e. no load section carries more than 8 fragment reads, none of the 8-read sections more than 2 DMA pieces.
+// Every LDS region is refilled (for K-tile t+2, same buffer) in the phase after its last read.  Issue order per K-tile:
+// A-rows-0-63 x2, W-half-0 x2, W-half-1 x2, A-rows-64-127 x2 (prologue: K-tiles 0 and 1 in that order); the counts of the
+// waits are "everything but the pieces issued after the one needed".
+// RAW: a wait sits in a load section, before a barrier every wave passes, and the data is first read one phase later (group 1
+// runs one barrier behind: a wait placed after the MFMAs would not yet have been executed by it).  WAR: every ds_read is
+// retired (lgkmcnt(0)) before the barrier that ends its load section; the refill is issued one phase later.
 #include <stdlib.h>
 
 #include "common.h"
@@ -32,6 +42,16 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 
 constexpr int BM = 256, BN = 256, HALF = 128 * 128, KBUF = 4 * HALF;   // 16 KiB half-tile, 64 KiB K-tile buffer
 constexpr int LDS_MAIN = 2 * KBUF, LDS_EPI = 8 * 64 * 68 * 4, LDS_BYTES = LDS_EPI > LDS_MAIN ? LDS_EPI : LDS_MAIN;
+
+// patch write -> read (and read -> next write) inside ONE wave: the LDS executes a wave's operations in order, only the
+// compiler must not reorder them.  (A workgroup-scope fence here also emits vmcnt(0): the second half of the epilogue would
+// wait for the global stores of the first.)
+#define MEDP_WAVE_LDS_SYNC()                        \
+    do {                                            \
+        asm volatile("" ::: "memory");              \
+        __builtin_amdgcn_wave_barrier();            \
+        asm volatile("" ::: "memory");              \
+    } while (0)
 
 #define MEDP_BAR()                                  \
     do {                                            \
@@ -90,18 +110,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v6_kernel(const MedpGemmA
             a_src[h][j] = ra < p.M ? A + (size_t)ra * p.lda + schunk * 8 : nullptr;
             w_src[h][j] = rw < p.N ? W + (size_t)rw * p.ldw + schunk * 8 : nullptr;
         }
-    // which = 0: A-lo, 1: A-hi, 2: W-lo, 3: W-hi of K-tile kt -> buffer kt & 1
-    auto stage_half = [&](int kt, int which) {
-        char* dst = smem + (kt & 1) * KBUF + which * HALF + wave * 1024;
+    // piece j (rows 64 j .. 64 j + 63) of half-tile `which` (0: A rows 0-127, 1: A rows 128-255, 2: W rows 0-127, 3: W rows
+    // 128-255) of K-tile kt -> buffer kt & 1; past K (the tail of the stream) the source is the zero chunk, counts stay uniform
+    auto stage_piece = [&](int kt, int which, int j) {
+        char* dst = smem + (kt & 1) * KBUF + which * HALF + wave * 1024 + j * 8192;
         const int k0 = kt * 64;
         const bool kin = k0 + schunk * 8 < p.K;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const bf16_t* base = which < 2 ? a_src[which & 1][j] : w_src[which & 1][j];
-            const bf16_t* src = (base != nullptr && kin) ? base + k0 : zero;
-            glds16(src, dst + j * 8192);
-        }
+        const bf16_t* base = which < 2 ? a_src[which & 1][j] : w_src[which & 1][j];
+        glds16((base != nullptr && kin) ? base + k0 : zero, dst);
     };
+    auto stage_a = [&](int kt, int j) { stage_piece(kt, 0, j); stage_piece(kt, 1, j); };
+    auto stage_w = [&](int kt, int h) { stage_piece(kt, 2 + h, 0); stage_piece(kt, 2 + h, 1); };
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -109,14 +128,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v6_kernel(const MedpGemmA
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // prologue: K-tile 0 complete + the W halves of K-tile 1 (what the steady-state stream would have issued by now)
-    stage_half(0, 2);
-    stage_half(0, 3);
-    stage_half(0, 0);
-    stage_half(0, 1);
-    stage_half(1, 2);
-    stage_half(1, 3);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // prologue: K-tiles 0 and 1, in the order of the steady-state stream
+    stage_a(0, 0); stage_w(0, 0); stage_w(0, 1); stage_a(0, 1);
+    stage_a(1, 0); stage_w(1, 0); stage_w(1, 1); stage_a(1, 1);
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // A rows 0-63 and W of K-tile 0
 
     // fragment read addresses: row = base + 16*i + fr, chunk (kh*4 + kq) ^ (row & 7); row & 7 == fr & 7 (bases are multiples of 16)
     const int sw = fr & 7;
@@ -124,7 +139,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v6_kernel(const MedpGemmA
     const int fw_off = 2 * HALF + (wn >> 1) * HALF + ((wn & 1) * 64 + fr) * 128;
     const int ch0 = ((0 + kq) ^ sw) << 4, ch1 = ((4 + kq) ^ sw) << 4;
 
-    bf16x8 fa[4][2], fw0[2][2], fw1[2][2];
+    bf16x8 fa[4][2], fw0a[2][2], fw0b[2][2], fw1[2][2];      // two W0 sets: K-tile t+1's is read while K-tile t's still multiplies
     auto read_a = [&](const char* buf, int a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -157,39 +172,46 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v6_kernel(const MedpGemmA
         __builtin_amdgcn_s_setprio(0);
     };
 
-    MEDP_BAR();                    // K-tile 0 visible to everyone
+    MEDP_BAR();                    // K-tile 0 (A rows 0-63, W) visible to everyone
+    read_w(smem, 0, fw0a);
     if (wm == 1) MEDP_BAR();       // group 1 runs one barrier behind (group 0 pays its extra barrier after the loop)
 
-    for (int kt = 0; kt < nkt; ++kt) {
+    auto ktile = [&](int kt, const bf16x8 (*fw0)[2], bf16x8 (*fw0n)[2]) {
         const char* buf = smem + (kt & 1) * KBUF;
         // ---- P1
-        read_w(buf, 0, fw0);
         read_a(buf, 0);
-        stage_half(kt + 1, 0);
         __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0), vmcnt/expcnt untouched
         MEDP_BAR();
         mma(0, 0, fw0);
         MEDP_BAR();
         // ---- P2
         read_w(buf, 1, fw1);
-        stage_half(kt + 1, 1);
+        stage_a(kt + 2, 0);
         __builtin_amdgcn_s_waitcnt(0xc07f);
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   // A rows 64-127 of K-tile kt (issued in P4(kt-2)) have landed
         MEDP_BAR();
         mma(0, 1, fw1);
         MEDP_BAR();
         // ---- P3
         read_a(buf, 1);
-        stage_half(kt + 2, 2);
+        stage_w(kt + 2, 0);
         __builtin_amdgcn_s_waitcnt(0xc07f);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // W (and A rows 0-63) of K-tile kt+1 (issued in P2..P4(kt-1)) have landed
         MEDP_BAR();
         mma(1, 1, fw1);
         MEDP_BAR();
         // ---- P4
-        stage_half(kt + 2, 3);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but W-lo/W-hi(kt+2): K-tile kt+1 has landed
+        read_w(smem + ((kt + 1) & 1) * KBUF, 0, fw0n);
+        stage_w(kt + 2, 1);
+        stage_a(kt + 2, 1);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
         MEDP_BAR();
         mma(1, 0, fw0);
         MEDP_BAR();
+    };
+    for (int kt = 0; kt < nkt; kt += 2) {
+        ktile(kt, fw0a, fw0b);
+        if (kt + 1 < nkt) ktile(kt + 1, fw0b, fw0a);
     }
     if (wm == 0) MEDP_BAR();
 
@@ -223,9 +245,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v6_kernel(const MedpGemmA
         for (int i4 = 0; i4 < 4; ++i4)
 #pragma unroll
             for (int j = 0; j < 4; ++j) *(f32x4*)(wl + (i4 * 16 + fr) * 68 + j * 16 + kq * 4) = acc[half * 4 + i4][j];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        MEDP_WAVE_LDS_SYNC();
         if (half == 0 && has_res) load_res(1);      // second half's residual flies while the first half is stored
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
@@ -249,9 +269,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v6_kernel(const MedpGemmA
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        MEDP_WAVE_LDS_SYNC();
     }
 }
 

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""v7 (persistent v6, gemm_bf16_v7.hip) must reproduce v6 BIT FOR BIT (same K order per tile, same epilogue) on every shape it
+is eligible for — eager, repeated (ticket blocks re-arm themselves), on two streams at once, and captured in a graph.
+Runs itself twice (MEDP_GEMM_V7=1 / 0) and compares the output digests; each run also checks against an fp32 product."""
+import hashlib, json, os, subprocess, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+SHAPES = [(16448, 2304, 768), (16448, 3072, 768), (16384, 2304, 768), (8192, 4096, 1024), (16448, 2304, 256),
+          (16500, 2300, 512), (70000, 1024, 256), (16448, 3072, 3072)]
+
+
+def child():
+    import torch
+    from multimodal_edema_prediction_amd import functional as Fn
+    torch.manual_seed(0)
+    dev = "cuda"
+    out = {}
+    def digest(t): return hashlib.sha256(t.detach().cpu().contiguous().view(torch.uint8).numpy().tobytes()).hexdigest()[:16]
+    for (m, n, k) in SHAPES:
+        a = torch.randn(m, k, device=dev).bfloat16(); w = torch.randn(n, k, device=dev).bfloat16()
+        bias = torch.randn(n, device=dev); scale = torch.rand(n, device=dev) + 0.5
+        ref0 = a.float() @ w.float().T
+        key = f"{m}x{n}x{k}"
+        y0 = Fn.gemm(a, w, out_dtype=torch.float32)
+        e0 = (y0 - ref0).abs().max().item()
+        y1 = Fn.gemm(a, w, bias=bias, act=1, out_dtype=torch.bfloat16)
+        ref1 = torch.nn.functional.gelu(ref0 + bias)
+        e1 = (y1.float() - ref1).abs().max().item() / max(1.0, ref1.abs().max().item())
+        y2 = Fn.gemm(a, w, bias=bias, scale=scale, out_dtype=torch.bfloat16)
+        d = [digest(y0), digest(y1), digest(y2)]
+        # repeated launches: every one must give the same bits (ticket blocks re-arm; ring wraps after 1024 launches)
+        same = True
+        for _ in range(30):
+            same &= bool(torch.equal(Fn.gemm(a, w, bias=bias, act=1, out_dtype=torch.bfloat16), y1))
+        # two streams at once
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s1): z1 = [Fn.gemm(a, w, bias=bias, act=1, out_dtype=torch.bfloat16) for _ in range(4)]
+        with torch.cuda.stream(s2): z2 = [Fn.gemm(a, w, out_dtype=torch.float32) for _ in range(4)]
+        torch.cuda.synchronize()
+        same &= all(torch.equal(z, y1) for z in z1) and all(torch.equal(z, y0) for z in z2)
+        # captured
+        yg = torch.empty_like(y1)
+        g = torch.cuda.CUDAGraph()
+        sg = torch.cuda.Stream()
+        with torch.cuda.stream(sg):
+            Fn.gemm(a, w, bias=bias, act=1, out=yg)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=sg):
+                Fn.gemm(a, w, bias=bias, act=1, out=yg)
+                Fn.gemm(a, w, bias=bias, act=1, out=yg)
+        for _ in range(5):
+            yg.zero_(); g.replay(); torch.cuda.synchronize()
+            same &= bool(torch.equal(yg, y1))
+        ok = e0 <= 1e-3 * k ** 0.5 + 1e-3 and e1 <= 2e-2 and same
+        out[key] = {"digest": d, "err": [e0, e1], "stable": same, "ok": ok}
+        print(key, out[key], file=sys.stderr, flush=True)
+    # the ring: > 1024 eager launches on one shape
+    m, n, k = SHAPES[0]
+    a = torch.randn(m, k, device=dev).bfloat16(); w = torch.randn(n, k, device=dev).bfloat16()
+    y = Fn.gemm(a, w, out_dtype=torch.bfloat16)
+    wrap = True
+    for i in range(1100):
+        z = Fn.gemm(a, w, out_dtype=torch.bfloat16)
+        if i % 100 == 99: wrap &= bool(torch.equal(z, y))
+    out["ring_wrap"] = {"ok": wrap, "digest": [digest(y)]}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "child":
+        child()
+        sys.exit(0)
+    res = {}
+    for v in ("1", "0"):
+        env = dict(os.environ, MEDP_GEMM_V7=v)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, stdout=subprocess.PIPE, text=True, timeout=900)
+        if r.returncode != 0:
+            print(f"MEDP_GEMM_V7={v}: child failed rc={r.returncode}"); sys.exit(1)
+        res[v] = json.loads(r.stdout.strip().splitlines()[-1])
+    bad = 0
+    for key in res["1"]:
+        a, b = res["1"][key], res["0"][key]
+        same = a["digest"] == b["digest"]
+        good = same and a["ok"] and b["ok"]
+        bad += not good
+        print(f"{key:22s} v7==v6 bitwise: {same}   v7 ok: {a['ok']}   v6 ok: {b['ok']}")
+    print("FAILED" if bad else "ALL OK")
+    sys.exit(1 if bad else 0)
