@@ -246,7 +246,7 @@ def main():
                        "captured HIP graph replay (graph_step.py), two-stream step" if args.no_pipeline else
                        "captured HIP graph replay (graph_step.py): two-stream step + frozen CXR encoder of batch k+1 run beside the "
                        "step of batch k (one encoder forward, one fusion fwd/bwd and one update per replay; 4 distinct batches rotate)")},
-        "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_v6_kernel<1> (CXR-encoder block GEMMs: qkv/proj/fc1/fc2; 256x256x64 tiles, 8 waves ping-pong, 128x64 per wave)",
+        "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_v6_kernel<1> / gemm_bf16_nt_v7_kernel<1> (CXR-encoder block GEMMs: proj, fc2 / qkv, fc1 — one K-loop: 256x256x64 tiles, 8 waves ping-pong, 128x64 per wave; v7 = persistent over the tile list)",
                      "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                      "traffic": traffic, "launches": int(n_l.value),
                      "avg_launch_us": round(ms.value * 1e3 / max(n_l.value, 1), 2),

@@ -14,15 +14,14 @@
 // MFMA quadrants: P1 (A0,W0)  P2 (A0,W1)  P3 (A1,W1)  P4 (A1,W0).
 // Phase plan of K-tile t (per wave; in-kernel phase clocks, tools/trace_gemm_v7.py --phases, decided it: a load section with
 // 12 ds_read_b128 took 670 ticks against ~330 for the 16 MFMAs it has to hide behind, one with 8 or 4 reads 300-360):
-//     P1: read A rows 0-63 (8)                            MFMA (A0, W0)
-//     P2: read W1 (4),            DMA A rows 0-63 (t+2)   MFMA (A0, W1)      wait vmcnt(10): A rows 64-127 of K-tile t
-//     P3: read A rows 64-127 (8), DMA W half 0 (t+2)      MFMA (A1, W1)      wait vmcnt(6):  W of K-tile t+1
+//     P1: read A rows 0-63 (8),   DMA A rows 64-127 (t+1)   MFMA (A0, W0)
+//     P2: read W1 (4),            DMA A rows 0-63 (t+2)     MFMA (A0, W1)    wait vmcnt(10): A rows 64-127 of K-tile t
+//     P3: read A rows 64-127 (8), DMA W half 0 (t+2)        MFMA (A1, W1)    wait vmcnt(6):  W of K-tile t+1
 //     P4: read W0 of K-TILE t+1 (4) into the other W0 register set,
-//                                 DMA W half 1, A rows 64-127 (t+2)          MFMA (A1, W0)
-// i.e. no load section carries more than 8 fragment reads, none of the 8-read sections more than 2 DMA pieces.
-// Every LDS region is refilled (for K-tile t+2, same buffer) in the phase after its last read.  Issue order per K-tile:
-// A-rows-0-63 x2, W-half-0 x2, W-half-1 x2, A-rows-64-127 x2 (prologue: K-tiles 0 and 1 in that order); the counts of the
-// waits are "everything but the pieces issued after the one needed".
+//                                 DMA W half 1 (t+2)        MFMA (A1, W0)
+// i.e. no load section carries more than 8 fragment reads or more than 2 DMA pieces (4 pieces + 4 reads in one section cost
+// 560-700 ticks).  Every LDS region is refilled (same buffer) one or two phases after its last read.  The counts of the
+// waits are "everything but the pieces issued after the one needed" (2 pieces per phase, in the order above).
 // RAW: a wait sits in a load section, before a barrier every wave passes, and the data is first read one phase later (group 1
 // runs one barrier behind: a wait placed after the MFMAs would not yet have been executed by it).  WAR: every ds_read is
 // retired (lgkmcnt(0)) before the barrier that ends its load section; the refill is issued one phase later.
@@ -130,8 +129,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v6_kernel(const MedpGemmA
 
     // prologue: K-tiles 0 and 1, in the order of the steady-state stream
     stage_a(0, 0); stage_w(0, 0); stage_w(0, 1); stage_a(0, 1);
-    stage_a(1, 0); stage_w(1, 0); stage_w(1, 1); stage_a(1, 1);
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // A rows 0-63 and W of K-tile 0
+    stage_a(1, 0); stage_w(1, 0); stage_w(1, 1);           // (A rows 64-127 of K-tile 1 follow in P1 of K-tile 0)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // A rows 0-63 and W of K-tile 0
 
     // fragment read addresses: row = base + 16*i + fr, chunk (kh*4 + kq) ^ (row & 7); row & 7 == fr & 7 (bases are multiples of 16)
     const int sw = fr & 7;
@@ -180,6 +179,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v6_kernel(const MedpGemmA
         const char* buf = smem + (kt & 1) * KBUF;
         // ---- P1
         read_a(buf, 0);
+        stage_a(kt + 1, 1);
         __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0), vmcnt/expcnt untouched
         MEDP_BAR();
         mma(0, 0, fw0);
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v6_kernel(const MedpGemmA
         read_w(buf, 1, fw1);
         stage_a(kt + 2, 0);
         __builtin_amdgcn_s_waitcnt(0xc07f);
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   // A rows 64-127 of K-tile kt (issued in P4(kt-2)) have landed
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   // A rows 64-127 of K-tile kt (issued in P1(kt-1)) have landed
         MEDP_BAR();
         mma(0, 1, fw1);
         MEDP_BAR();
@@ -203,7 +203,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v6_kernel(const MedpGemmA
         // ---- P4
         read_w(smem + ((kt + 1) & 1) * KBUF, 0, fw0n);
         stage_w(kt + 2, 1);
-        stage_a(kt + 2, 1);
         __builtin_amdgcn_s_waitcnt(0xc07f);
         MEDP_BAR();
         mma(1, 0, fw0);

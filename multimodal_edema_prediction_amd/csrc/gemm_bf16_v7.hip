@@ -129,19 +129,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v7_kernel(const MedpGemmA
     auto set_n = [&](int nn) { n_src = nn; w_off = (unsigned)(nn + srow) * (unsigned)p.ldw + (unsigned)(schunk * 8); };
     set_m(m0);
     set_n(n0);
-    // which = 0: A-lo, 1: A-hi, 2: W-lo, 3: W-hi of the K-tile at element offset k0 -> K buffer `b`
-    auto stage_half = [&](int k0, int b, int which) {
-        char* dst = smem + b * KBUF + which * HALF + wave * 1024;
+    // piece j (rows 64 j .. 64 j + 63) of half-tile `which` (0: A rows 0-127, 1: A rows 128-255, 2: W rows 0-127, 3: W rows
+    // 128-255) of the K-tile at element offset k0 of the CURRENT source tile -> K buffer `b`
+    auto stage_piece = [&](int k0, int b, int which, int j) {
+        char* dst = smem + b * KBUF + which * HALF + wave * 1024 + j * 8192;
         const bool kin = k0 + schunk * 8 < p.K;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = (which < 2 ? m_src : n_src) + (which & 1) * 128 + j * 64 + srow;
-            const bool ok = kin && r < (which < 2 ? p.M : p.N);
-            const unsigned off = (which < 2 ? a_off + ((which & 1) * 2 + j) * lda64 : w_off + ((which & 1) * 2 + j) * ldw64) + (unsigned)k0;
-            const bf16_t* live = (which < 2 ? A : W) + off;
-            glds16(ok ? live : zero, dst + j * 8192);
-        }
+        const int r = (which < 2 ? m_src : n_src) + (which & 1) * 128 + j * 64 + srow;
+        const bool ok = kin && r < (which < 2 ? p.M : p.N);
+        const unsigned off = (which < 2 ? a_off + ((which & 1) * 2 + j) * lda64 : w_off + ((which & 1) * 2 + j) * ldw64) + (unsigned)k0;
+        const bf16_t* live = (which < 2 ? A : W) + off;
+        glds16(ok ? live : zero, dst);
     };
+    auto stage_a = [&](int k0, int b, int j) { stage_piece(k0, b, 0, j); stage_piece(k0, b, 1, j); };
+    auto stage_w = [&](int k0, int b, int h) { stage_piece(k0, b, 2 + h, 0); stage_piece(k0, b, 2 + h, 1); };
     typedef __attribute__((address_space(3))) volatile int lds_int;
     lds_int* mailbox = (lds_int*)(__attribute__((address_space(3))) char*)(smem + MAILBOX);
     // debug timeline: wave 0 stamps the 100-MHz wall clock into LDS at four points of every tile; dumped at exit
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v7_kernel(const MedpGemmA
     const int fw_off = 2 * HALF + (wn >> 1) * HALF + ((wn & 1) * 64 + fr) * 128;
     const int ch0 = ((0 + kq) ^ sw) << 4, ch1 = ((4 + kq) ^ sw) << 4;
 
-    bf16x8 fa[4][2], fw0[2][2], fw1[2][2];
+    bf16x8 fa[4][2], fw0a[2][2], fw0b[2][2], fw1[2][2];      // two W0 sets: K-tile t+1's is read while K-tile t's still multiplies
     auto read_a = [&](const char* buf, int a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -226,17 +226,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v7_kernel(const MedpGemmA
     // prologue of the FIRST tile: K-tile 0 and K-tile 1 complete — the state every later tile starts from
     stage_bias(n0, true, 0);
     draw_ticket();
-    stage_half(0, 0, 2);
-    stage_half(0, 0, 3);
-    stage_half(0, 0, 0);
-    stage_half(0, 0, 1);
-    stage_half(64, 1, 2);
-    stage_half(64, 1, 3);
-    stage_half(64, 1, 0);
-    stage_half(64, 1, 1);
+    stage_a(0, 0, 0); stage_w(0, 0, 0); stage_w(0, 0, 1); stage_a(0, 0, 1);        // the order of the steady-state stream
+    stage_a(64, 1, 0); stage_w(64, 1, 0); stage_w(64, 1, 1);                        // (A rows 64-127 of K-tile 1: P1 of K-tile 0)
     __builtin_amdgcn_s_waitcnt(0x0f70);                    // vmcnt(0)
     asm volatile("" : "+v"(ticket)::"memory");
     post_ticket();
+    bool first = true;
 
 #ifdef MEDP_V7_PHASE_TRACE
     unsigned pt_acc[17], pt_last = 0;
@@ -255,27 +250,27 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v7_kernel(const MedpGemmA
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){z, z, z, z};
+        if (first) read_w(smem, 0, fw0a);      // later tiles: read in P4 of the previous tile's last K-tile
+        first = false;
         if (wm == 1) MEDP_BAR();       // group 1 runs one barrier behind (group 0 pays its extra barrier after the loop)
 
 #ifdef MEDP_V7_PHASE_TRACE
         pt_last = (unsigned)__builtin_readcyclecounter();
 #endif
         int t_next = -1, m0n = 0, n0n = 0;
-#pragma clang loop unroll(disable)
-        for (int kt = 0; kt < nkt; ++kt) {
+        // one K-tile; the phase plan and the waits are those of gemm_bf16_v6.hip.  The stream runs two K-tiles ahead and from
+        // K-tile nkt-2 on belongs to the NEXT tile (its K-tiles 0 and 1; nobody: zero source): when the loop ends all of them but
+        // the last A piece are issued, and the W0 fragments of the next K-tile 0 are in registers.  Tiles start with those
+        // landed, so the waits of K-tile 0 are skipped: the first wait that covers the previous tile's output stores is P2 of
+        // K-tile 1.
+        auto ktile = [&](int kt, const bf16x8 (*fw0)[2], bf16x8 (*fw0n)[2]) {
             const char* buf = smem + (kt & 1) * KBUF;
-            if (kt == nkt - 2) {       // from here on the W stream belongs to the next tile (or to nobody: zero source)
-                t_next = __builtin_amdgcn_readfirstlane(mailbox[0]);
-                if (t_next >= 0) origin(t_next, m0n, n0n);
-                set_n(t_next >= 0 ? n0n : NOBODY);
-            }
-            if (kt == nkt - 1) set_m(t_next >= 0 ? m0n : NOBODY);
-            const int ka = kt + 1 < nkt ? (kt + 1) * 64 : 0;                     // A halves of K-tile kt+1 (next tile: its K-tile 0)
-            const int kw = kt + 2 < nkt ? (kt + 2) * 64 : (kt + 2 - nkt) * 64;   // W halves of K-tile kt+2 (next tile: K-tile 0 / 1)
+            const int k2 = kt + 2 < nkt ? (kt + 2) * 64 : (kt + 2 - nkt) * 64;
+            const int k1 = kt + 1 < nkt ? (kt + 1) * 64 : 0;
+            const int b2 = kt & 1;
             // ---- P1
-            read_w(buf, 0, fw0);
             read_a(buf, 0);
-            if (kt != 0) stage_half(ka, (kt + 1) & 1, 0);      // (K-tile 1's A halves were staged before the previous epilogue)
+            stage_a(k1, b2 ^ 1, 1);
             __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0), vmcnt/expcnt untouched
             PT(0);
             MEDP_BAR();
@@ -285,9 +280,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v7_kernel(const MedpGemmA
             MEDP_BAR();
             PT(3);
             // ---- P2
+            if (kt == nkt - 2) {       // from here on the stream reads the next tile (P1 above still staged this tile's last A piece)
+                t_next = __builtin_amdgcn_readfirstlane(mailbox[0]);
+                if (t_next >= 0) origin(t_next, m0n, n0n);
+                set_m(t_next >= 0 ? m0n : NOBODY);
+                set_n(t_next >= 0 ? n0n : NOBODY);
+            }
             read_w(buf, 1, fw1);
-            if (kt != 0) stage_half(ka, (kt + 1) & 1, 1);
+            stage_a(k2, b2, 0);
             __builtin_amdgcn_s_waitcnt(0xc07f);
+            if (kt >= 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   // A rows 64-127 of K-tile kt (issued in P1(kt-1)) have landed
             PT(4);
             MEDP_BAR();
             PT(5);
@@ -297,8 +299,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v7_kernel(const MedpGemmA
             PT(7);
             // ---- P3
             read_a(buf, 1);
-            stage_half(kw, kt & 1, 2);
+            stage_w(k2, b2, 0);
             __builtin_amdgcn_s_waitcnt(0xc07f);
+            if (kt >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // W (and A rows 0-63) of K-tile kt+1 have landed
             PT(8);
             MEDP_BAR();
             PT(9);
@@ -307,10 +310,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v7_kernel(const MedpGemmA
             MEDP_BAR();
             PT(11);
             // ---- P4
-            stage_half(kw, kt & 1, 3);
-            // all but the last two half-tiles: K-tile kt+1 has landed.  Not at kt = 0: K-tile 1 landed before the tile top, and
-            // the previous tile's output stores (older than anything this loop has issued) get until here + one K-tile to retire
-            if (kt != 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            read_w(smem + ((kt + 1) & 1) * KBUF, 0, fw0n);
+            stage_w(k2, b2, 1);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
             PT(12);
             MEDP_BAR();
             PT(13);
@@ -318,16 +320,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v7_kernel(const MedpGemmA
             PT(14);
             MEDP_BAR();
             PT(15);
+        };
+#pragma clang loop unroll(disable)
+        for (int kt = 0; kt < nkt; kt += 2) {
+            ktile(kt, fw0a, fw0b);
+            ktile(kt + 1, fw0b, fw0a);
         }
         if (wm == 0) MEDP_BAR();
 
-        // ---- between K-loops.  Everybody is past the last read of K buffer 1: its A halves take K-tile 1 of the next tile (its W
-        // halves and all of the next K-tile 0 are already in flight), so the next K-loop starts two K-tiles deep.
+        // ---- between K-loops: K-tiles 0 and 1 of the next tile are in flight; its bias slice and the ticket after it join them
         stamp(1, 0);
         draw_ticket();
         stage_bias(n0n, t_next >= 0, bias_cur ^ 1);
-        stage_half(64, 1, 0);
-        stage_half(64, 1, 1);
 
         // ---- epilogue: bias / GELU / bf16 pack on the accumulator layout (a lane holds 4 consecutive columns of one row), then a
         // 16-row x 64-column bf16 patch per wave through LDS so that every global store instruction writes whole 128-B rows
