@@ -34,6 +34,8 @@ const char* medp_arch(void);       /* "gfx950" */
  * projection (transformers modeling_dinov2.py:139,199-201,246,286,291), x_transformers to_q/k/v/out + ff
  * (duett/duett.py:95-105), img_proj / ts_proj / perceiver in_proj, out_proj, ff (model :566,:749-757,:1027).
  * epi: (+bias[n]) -> (act==1: GELU erf) -> (*scale[n], Dinov2 LayerScale :278) -> (+residual[m,n] fp32).
+ * (GELU: erf to 1.5e-7 for an fp32 result; the large-tile kernels use a degree-17 odd polynomial, |GELU error| <= 6.3e-5,
+ * where the result is rounded to bf16 anyway.)
  * Requirements: K, lda, ldw multiples of 8; N, ldc, ldr multiples of 4; 16-B aligned bases.  M, N, K ragged OK. */
 int medp_gemm_bf16_nt(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldw, int ldc,
                       const float* bias, const float* scale, const float* residual, int ldr, int act, int out_bf16,

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v6_kernel(const MedpGemmA
             f32x4 v = *(const f32x4*)(wl + rr * 68 + ec);
             if (m < p.M && n < p.N) {
                 v += bias4;
-                if (p.act == 1) v = gelu_erf4(v);
+                if (p.act == 1) v = p.out_bf16 ? gelu_bf16_4(v) : gelu_erf4(v);
                 v *= scale4;
                 if (has_res) v += res[half][it];
                 if (p.out_bf16) {

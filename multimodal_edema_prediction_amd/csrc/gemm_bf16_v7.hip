@@ -349,7 +349,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v7_kernel(const MedpGemmA
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 f32x4 v = acc[i][j] + bj[j];
-                if (p.act == 1) v = gelu_erf4(v);
+                if (p.act == 1) v = gelu_bf16_4(v);
                 *(u32x2*)(wl + fr * PROW + j * 32 + kq * 8) = (u32x2){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
             }
             MEDP_WAVE_LDS_SYNC();
