@@ -263,6 +263,23 @@ int medp_psi_assemble_bwd(const float* xs_ts, const float* dpsi, float* d_var_ou
 int medp_axis_swap(const float* in, float* out, int B, int A1, int A2, int E, void* stream);
 int medp_add_bcast(const float* a, const float* b, float* out, long long per_batch, int B, int broadcast_b, void* stream);
 
+/* ---- LocalTrajectoryEncoder (models/main_architecture_duett.py:1242-1391) -------------------------------
+ * The Linear / LayerNorm / GELU stages of the module are the kernels above; these are the rest.
+ * medp_traj_features: x [B,T,2V] fp32 (values | counts) -> out [B*V, T, 8] fp32 = {value (0 where unobserved), observed,
+ *   log1p(count)/ln 16, steps since the previous observation / T, (T - t) / T, 0, 0, 0}  (:1316-1330, :1342-1358; the five
+ *   features padded to 8 so that Linear(5, d) runs as a K = 8 GEMM).
+ * medp_gru_fwd: one-layer batch-first nn.GRU, h0 = 0 (:1297-1303, :1366), hidden size d = 128 only (anything else: rc < 0).
+ *   gi [S,T,3d] fp32 = x_t W_ih^T + b_ih (gate order r | z | n), whh_bf16 [3d,d], bhh [3d] -> hseq [S,T,d]; gates [S,T,3d]
+ *   (r | z | n) and hn [S,T,d] (= W_hn h + b_hn) are saved for the backward (both null: inference).
+ * medp_gru_bwd: dh [S,T,d] (gradient w.r.t. every h_t) -> dgi [S,T,3d], dghn [S,T,d] (gradient w.r.t. W_hn h + b_hn) and
+ *   dgh_bf16 [S,T,3d] (r | z | n parts of the gradient w.r.t. h W_hh^T + b_hh; dW_hh = dgh^T h_prev is a medp_gemm_bf16_tn).
+ *   whh_t_bf16 [d,3d] = W_hh transposed. */
+int medp_traj_features(const float* x, float* out, int B, int T, int V, void* stream);
+int medp_gru_fwd(const float* gi, const void* whh_bf16, const float* bhh, float* hseq, float* gates, float* hn, int S, int T, int d,
+                 void* stream);
+int medp_gru_bwd(const float* dh, const float* gates, const float* hn, const float* hseq, const void* whh_t_bf16, float* dgi,
+                 float* dghn, void* dgh_bf16, int S, int T, int d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -113,6 +113,9 @@ SIGNATURES = {
     "medp_bce_mean": (I, [P, P, P, P, P, I, P]),
     "medp_adamw_chunk_elems": (I, []),
     "medp_adamw_multi": (I, [P, P, P, I, F, F, F, I, P, F, P]),
+    "medp_traj_features": (I, [P, P, I, I, I, P]),
+    "medp_gru_fwd": (I, [P, P, P, P, P, P, I, I, I, P]),
+    "medp_gru_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
     "medp_rng_set_epoch_ptr": (I, [P]),
     "medp_counter_advance": (I, [P, P]),
 }

@@ -19,6 +19,7 @@ from . import autograd_ops as A
 from . import functional as Fn
 from .cxr import CXREncoder, Dinov2Cfg  # noqa: F401  (re-exported)
 from .duett import DuettFeatureExtractor, load_duett_backbone  # noqa: F401  (re-exported)
+from .trajectory import LocalTrajectoryEncoder  # noqa: F401  (re-exported; model file :1242-1391)
 
 __all__ = ["DuettFeatureExtractor", "load_duett_backbone", "CXREncoder", "PatchDualPathologyPerceiver", "_PerceiverBlock",
            "TeacherModel", "StudentModel"]
