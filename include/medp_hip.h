@@ -132,6 +132,12 @@ size_t medp_vit_workspace_bytes(const MedpVitWeights* host_w, int B, int H, int 
 /* pixels fp32 [B,3,H,W] -> tokens_f32 [B, P+1, hidden] (may be NULL) and/or tokens_bf16 (may be NULL) after the final LN */
 int medp_vit_forward(const MedpVitWeights* host_w, const float* pixels, int B, int H, int W, float* tokens_f32,
                      void* tokens_bf16, void* workspace, size_t workspace_bytes, void* stream);
+/* The same forward in pieces: the embedding stage runs when first_layer == 0, encoder layers [first_layer, last_layer), the final
+ * LayerNorm (and the outputs) when last_layer == n_layers.  Between calls the fp32 token stream lives in `workspace`, which
+ * the caller must leave untouched.  (graph_step.py splits the frozen encoder of the NEXT batch across the two captured graphs
+ * of a multi-GPU step, so that the gradient all-reduce and the optimiser run beside encoder layers instead of after them.) */
+int medp_vit_forward_part(const MedpVitWeights* w, const float* pixels, int B, int H, int W, float* tokens_f32, void* tokens_bf16,
+                          void* workspace, size_t workspace_bytes, int first_layer, int last_layer, void* stream);
 
 /* ---- whole-module forward of the DuETT backbone in inference form: DuettFeatureExtractor.encode (model :31-94) -----
  * BatchNorm layers are folded by the caller into (scale, shift) = (w/sqrt(var+eps), b - mean*scale): eval-mode

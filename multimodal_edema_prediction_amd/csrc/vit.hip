@@ -38,8 +38,18 @@ extern "C" size_t medp_vit_workspace_bytes(const MedpVitWeights* w, int B, int H
 
 extern "C" int medp_vit_forward(const MedpVitWeights* w, const float* pixels, int B, int H, int W, float* tokens_f32,
                                 void* tokens_bf16, void* workspace, size_t workspace_bytes, void* stream) {
+    MEDP_CHECK_ARG(w, "vit_forward: null argument");
+    return medp_vit_forward_part(w, pixels, B, H, W, tokens_f32, tokens_bf16, workspace, workspace_bytes, 0, w->n_layers, stream);
+}
+
+extern "C" int medp_vit_forward_part(const MedpVitWeights* w, const float* pixels, int B, int H, int W, float* tokens_f32,
+                                     void* tokens_bf16, void* workspace, size_t workspace_bytes, int first_layer, int last_layer,
+                                     void* stream) {
     MEDP_CHECK_ARG(w && pixels && workspace, "vit_forward: null argument");
-    MEDP_CHECK_ARG(tokens_f32 || tokens_bf16, "vit_forward: no output requested");
+    MEDP_CHECK_ARG(0 <= first_layer && first_layer <= last_layer && last_layer <= w->n_layers,
+                   "vit_forward: bad layer range [%d, %d) of %d", first_layer, last_layer, w->n_layers);
+    const bool embed = first_layer == 0, finish = last_layer == w->n_layers;
+    MEDP_CHECK_ARG(!finish || tokens_f32 || tokens_bf16, "vit_forward: no output requested");
     MEDP_CHECK_ARG(w->hidden == w->n_heads * 64, "vit_forward: head dim must be 64 (hidden %d, heads %d)", w->hidden, w->n_heads);
     MEDP_CHECK_ARG(H >= w->patch && W >= w->patch, "vit_forward: image %dx%d smaller than one patch (%d)", H, W, w->patch);
     const VitWs ws = plan(w, B, H, W);
@@ -55,17 +65,19 @@ extern "C" int medp_vit_forward(const MedpVitWeights* w, const float* pixels, in
     void* att = base + ws.att;
     void* f = base + ws.f;
 
-    MEDP_TRY(medp_im2col_patch(pixels, a0, B, 3, H, W, w->patch, w->patch_kpad, stream));
-    MEDP_TRY(medp_gemm_bf16_nt(a0, w->patch_w, patch, B * P, D, w->patch_kpad, w->patch_kpad, w->patch_kpad, D, w->patch_b,
-                               nullptr, nullptr, 0, 0, 0, stream));
-    const float* pos_used = w->pos;
-    if (!(gh == w->pos_side && gw == w->pos_side)) {
-        MEDP_TRY(medp_pos_embed_bicubic(w->pos, pos, w->pos_side, gh, gw, D, stream));
-        pos_used = pos;
+    if (embed) {
+        MEDP_TRY(medp_im2col_patch(pixels, a0, B, 3, H, W, w->patch, w->patch_kpad, stream));
+        MEDP_TRY(medp_gemm_bf16_nt(a0, w->patch_w, patch, B * P, D, w->patch_kpad, w->patch_kpad, w->patch_kpad, D, w->patch_b,
+                                   nullptr, nullptr, 0, 0, 0, stream));
+        const float* pos_used = w->pos;
+        if (!(gh == w->pos_side && gw == w->pos_side)) {
+            MEDP_TRY(medp_pos_embed_bicubic(w->pos, pos, w->pos_side, gh, gw, D, stream));
+            pos_used = pos;
+        }
+        MEDP_TRY(medp_vit_assemble(patch, w->cls, pos_used, x, B, P, D, stream));
     }
-    MEDP_TRY(medp_vit_assemble(patch, w->cls, pos_used, x, B, P, D, stream));
     const float scale = 0.125f;   // 64^-0.5
-    for (int l = 0; l < w->n_layers; ++l) {
+    for (int l = first_layer; l < last_layer; ++l) {
         const MedpVitLayer& L = w->layers[l];
         MEDP_TRY(medp_layernorm_fwd(x, D, L.ln1_w, L.ln1_b, h, D, 1, nullptr, nullptr, M, D, w->ln_eps, stream));
         MEDP_TRY(medp_gemm_bf16_nt_tagged(1, h, L.qkv_w, qkv, M, 3 * D, D, D, D, 3 * D, L.qkv_b, nullptr, nullptr, 0, 0, 1, stream));
@@ -76,6 +88,7 @@ extern "C" int medp_vit_forward(const MedpVitWeights* w, const float* pixels, in
         MEDP_TRY(medp_gemm_bf16_nt_tagged(1, h, L.fc1_w, f, M, w->mlp_hidden, D, D, D, w->mlp_hidden, L.fc1_b, nullptr, nullptr, 0, 1, 1, stream));
         MEDP_TRY(medp_gemm_bf16_nt_tagged(1, f, L.fc2_w, x, M, D, w->mlp_hidden, w->mlp_hidden, w->mlp_hidden, D, L.fc2_b, L.ls2, x, D, 0, 0, stream));
     }
+    if (!finish) return 0;                 // the fp32 token stream stays in the workspace for the call that continues
     if (tokens_f32)
         MEDP_TRY(medp_layernorm_fwd(x, D, w->final_ln_w, w->final_ln_b, tokens_f32, D, 0, nullptr, nullptr, M, D, w->ln_eps, stream));
     if (tokens_bf16)

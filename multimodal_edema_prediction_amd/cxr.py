@@ -146,8 +146,10 @@ class Dinov2Backbone(nn.Module):
         self._prep, self._prep_key = (w, layers, keep), key
         return self._prep
 
-    def forward(self, pixel_values: torch.Tensor, want_f32: bool = True, want_bf16: bool = False):
-        """pixel_values fp32 [B,3,H,W] -> last_hidden_state after the final LayerNorm ([B, P+1, hidden])."""
+    def forward(self, pixel_values: torch.Tensor, want_f32: bool = True, want_bf16: bool = False, layers=None):
+        """pixel_values fp32 [B,3,H,W] -> last_hidden_state after the final LayerNorm ([B, P+1, hidden]).
+        `layers=(first, last)` (frozen path only): run that piece of the encoder (medp_vit_forward_part); the outputs exist
+        only for the piece that ends at the last layer, the token stream waits in this module's workspace in between."""
         abi.require_gpu()
         if pixel_values.dim() != 4 or pixel_values.shape[1] != self.cfg.num_channels:
             raise ValueError("Make sure that the channel dimension of the pixel values match with the one set in the "
@@ -165,10 +167,12 @@ class Dinov2Backbone(nn.Module):
         if self._ws is None or self._ws.numel() < need or self._ws.device != px.device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=px.device)
         D = self.cfg.hidden_size
-        out32 = torch.empty((B, P + 1, D), dtype=torch.float32, device=px.device) if want_f32 else None
-        out16 = torch.empty((B, P + 1, D), dtype=torch.bfloat16, device=px.device) if want_bf16 else None
-        check(lib().medp_vit_forward(ctypes.byref(w), ptr(px), B, H, W, ptr(out32), ptr(out16), ptr(self._ws), need, stream()),
-              "vit_forward")
+        first, last = (0, self.cfg.num_hidden_layers) if layers is None else layers
+        fin = last == self.cfg.num_hidden_layers
+        out32 = torch.empty((B, P + 1, D), dtype=torch.float32, device=px.device) if (want_f32 and fin) else None
+        out16 = torch.empty((B, P + 1, D), dtype=torch.bfloat16, device=px.device) if (want_bf16 and fin) else None
+        check(lib().medp_vit_forward_part(ctypes.byref(w), ptr(px), B, H, W, ptr(out32), ptr(out16), ptr(self._ws), need, first, last,
+                                          stream()), "vit_forward")
         return out32, out16
 
 
@@ -218,4 +222,11 @@ class CXREncoder(nn.Module):
         """Build-internal fast path: tokens as bf16 [B, P+1, D], directly consumable by the img_proj GEMM (fp32 tokens with a
         gradient when the encoder is being trained)."""
         _, t16 = self.backbone(pixel_values, want_f32=False, want_bf16=True)
+        return t16
+
+    def forward_bf16_part(self, pixel_values: torch.Tensor, first: int, last: int):
+        """A piece of the frozen encoder (layers [first, last)); returns the bf16 tokens from the piece that finishes it, else None."""
+        if any(p.requires_grad for p in self.backbone.parameters()):
+            raise RuntimeError("the encoder can only be run in pieces when it is frozen")
+        _, t16 = self.backbone(pixel_values, want_f32=False, want_bf16=True, layers=(first, last))
         return t16

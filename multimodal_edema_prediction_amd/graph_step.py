@@ -7,7 +7,12 @@ RNG epoch (`medp_rng_set_epoch_ptr`), the optimiser step count (`FusedAdamW.dev_
 (the descriptor table is re-uploaded from pinned host memory by a captured memcpy node).
 
 N > 1: forward+backward are one graph accumulating into a flat fp32 gradient arena, the arena is all-reduced by RCCL
-between the two replays (one collective, 14.8 MB), and the optimiser is a second graph.
+between the two replays (one collective, 14.8 MB), and the optimiser is a second graph.  With `pipeline_cxr` the frozen
+encoder of the next batch CAN be split across the two graphs (`MEDP_SPLIT_VIT_LAYERS=L`, `medp_vit_forward_part`: layers
+[0, L) beside forward/backward, layers [L, 12) beside the optimiser) so that the collective and the update need not wait for
+the whole encoder.  Measured on one GPU in the N > 1 arrangement it LOSES (L = 8 / 7 / 5: 10.2 / 9.9 / 9.5 k samples/s
+against 11.5 k with the encoder whole in the first graph, bit-identical results): the two branches of the step time-share
+the CUs rather than fill each other's gaps, so layers moved behind the optimiser simply run later.  Default 0 (whole).
 
 `pipeline_cxr=True` (software pipelining across steps): the CXR encoder is frozen, so its tokens for batch k+1 depend on
 nothing the training step of batch k produces.  The captured step then holds THREE parallel branches: the image half +
@@ -18,6 +23,8 @@ encoder pass is just shifted one batch ahead (the first batch's pass happens in 
 unpipelined step (tests/test_gpu_pipeline.py).
 """
 from __future__ import annotations
+
+import os
 
 import torch
 import torch.distributed as dist
@@ -55,6 +62,13 @@ class GraphedTeacherStep:
         if self.split:
             n = sum(p.numel() for p in self.params)
             self.flat_grad = torch.zeros(n, dtype=torch.float32, device=device)
+        # split + pipelined: encoder layers [0, vit_split) run in the forward/backward graph, the rest beside the optimiser
+        self.vit_split = 0
+        if self.split and self.pipeline:
+            n_layers = teacher.cxr.backbone.cfg.num_hidden_layers
+            self.vit_split = max(0, min(n_layers, int(os.environ.get("MEDP_SPLIT_VIT_LAYERS", "0"))))
+            if self.vit_split == n_layers:
+                self.vit_split = 0
         engine._set_train_with_frozen_eval(teacher)
         # warm-up on a side stream (allocator pools, lazy workspaces, optimiser state), as torch.cuda.graphs requires
         s = torch.cuda.Stream(device=device)
@@ -65,7 +79,7 @@ class GraphedTeacherStep:
                 self._advance()
                 self._fwd_bwd()
                 self._allreduce()
-                self.opt.step()
+                self._opt_step()
         torch.cuda.current_stream(device).wait_stream(s)
         torch.cuda.synchronize(device)
         self._zero_grads()
@@ -85,7 +99,7 @@ class GraphedTeacherStep:
                 self.out = self._fwd_bwd()
             self.g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_opt):
-                self.opt.step()
+                self._opt_step()
         torch.cuda.synchronize(device)
         self.opt._step = int(self.opt.dev_step.item())      # capture ran opt.step() on the host without executing it
 
@@ -110,7 +124,10 @@ class GraphedTeacherStep:
             cur = torch.cuda.current_stream(self.device)
             self.vit_stream.wait_stream(cur)
             with torch.cuda.stream(self.vit_stream), torch.no_grad():
-                tok_next = self.teacher.cxr.forward_bf16(self.pixels_next)          # batch k+1, beside batch k's step
+                if self.vit_split:
+                    self.teacher.cxr.forward_bf16_part(self.pixels_next, 0, self.vit_split)      # the rest: _opt_step
+                else:
+                    tok_next = self.teacher.cxr.forward_bf16(self.pixels_next)      # batch k+1, beside batch k's step
         out = self.teacher(tuple(self.x_ts[i] for i in range(B)), tuple(self.x_static[i] for i in range(B)),
                            tuple(self.bin_ends[i] for i in range(B)), self.pixels,
                            **({"_cxr_tokens16": self.tok_cur} if self.pipeline else {}))
@@ -118,10 +135,26 @@ class GraphedTeacherStep:
         losses["total"].backward()
         if self.pipeline:
             cur.wait_stream(self.vit_stream)
-            tok_next.record_stream(cur)
-            self.tok_cur.copy_(tok_next)          # after the backward: the weight-gradient GEMM of img_proj reads tok_cur
+            if not self.vit_split:
+                tok_next.record_stream(cur)
+                self.tok_cur.copy_(tok_next)      # after the backward: the weight-gradient GEMM of img_proj reads tok_cur
         return {"loss": losses["total"].detach(), "img_total": losses["img_total"], "ts_total": losses["ts_total"],
                 "fus_total": losses["fus_total"], "fusion_logits": out["fusion_logits"].detach(), "main_logit": out["main_logit"].detach()}
+
+    def _opt_step(self):
+        """The optimiser; in the split + pipelined step also the remaining encoder layers of the next batch, beside it."""
+        if not self.vit_split:
+            self.opt.step()
+            return
+        cur = torch.cuda.current_stream(self.device)
+        self.vit_stream.wait_stream(cur)
+        with torch.cuda.stream(self.vit_stream), torch.no_grad():
+            n_layers = self.teacher.cxr.backbone.cfg.num_hidden_layers
+            tok_next = self.teacher.cxr.forward_bf16_part(self.pixels_next, self.vit_split, n_layers)
+        self.opt.step()
+        cur.wait_stream(self.vit_stream)
+        tok_next.record_stream(cur)
+        self.tok_cur.copy_(tok_next)
 
     def _allreduce(self):
         if self.world > 1 and dist.is_initialized():

@@ -13,8 +13,12 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("split", [False, True])
-def test_pipelined_step_is_bit_identical(split):
+@pytest.mark.parametrize("split,vit_layers", [(False, None), (True, "0"), (True, "7"), (True, "4")])
+def test_pipelined_step_is_bit_identical(split, vit_layers, monkeypatch):
+    # vit_layers: how many encoder layers of the NEXT batch run in the forward/backward graph of the split (N > 1) step, the
+    # rest running beside the optimiser in the second graph (0: the whole encoder in the first graph)
+    if vit_layers is not None:
+        monkeypatch.setenv("MEDP_SPLIT_VIT_LAYERS", vit_layers)
     import test_gpu_model as T
     from multimodal_edema_prediction_amd.graph_step import GraphedTeacherStep
     from multimodal_edema_prediction_amd.losses_duett import DualPathologyLoss
