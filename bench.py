@@ -149,7 +149,10 @@ def main():
             pool_g = [dict(b, x_ts=torch.stack(tuple(b["x_ts"])), x_static=torch.stack(tuple(b["x_static"])),
                            bin_ends=torch.stack(tuple(b["bin_ends"]))) for b in pool]
         else:
-            pool_g = pool
+            # host batches as a DataLoader with pin_memory=True hands them over: pinned pages, per-sample tuples stacked by the collate
+            pool_g = [dict(b, x_ts=torch.stack(tuple(b["x_ts"])).pin_memory(), x_static=torch.stack(tuple(b["x_static"])).pin_memory(),
+                           bin_ends=torch.stack(tuple(b["bin_ends"])).pin_memory(), pixel_values=b["pixel_values"].pin_memory(),
+                           y_multi=b["y_multi"].float().pin_memory(), y_multi_mask=b["y_multi_mask"].float().pin_memory()) for b in pool]
         gstep = GraphedTeacherStep(teacher, loss_fn, opt, pool[0], device, world=2 if force_pg else world,
                                    pipeline_cxr=not (args.no_pipeline or args.unfreeze_cxr))
         if force_pg:
@@ -166,7 +169,8 @@ def main():
         _state = {"n": 0, "loss": float("nan")}
 
         def step(i):
-            out = gstep.step(pool_g[i % n_pool], pool_g[(i + 1) % n_pool])     # (batch to train on, batch the next call will bring)
+            out = gstep.step(pool_g[i % n_pool], pool_g[(i + 1) % n_pool],      # (batch to train on, batch the next call will bring,
+                             pool_g[(i + 2) % n_pool] if args.host_batch else None)   #  host batches: the one after, staged ahead)
             sched.step()
             k = _state["n"]
             _pin[k % 2].copy_(out["loss"], non_blocking=True)

@@ -44,3 +44,35 @@ def test_pipelined_step_is_bit_identical(split, vit_layers, monkeypatch):
     assert len(set(l0)) > 3                            # the batches really differ
     for k in p0:
         assert torch.equal(p0[k], p1[k]), k
+
+
+def test_staged_host_batches_give_the_same_steps():
+    """Host batches staged one call ahead on the copy stream (step(batch, next, after_next)) against device-resident batches:
+    same losses and parameters, bit for bit, including a broken announcement."""
+    import test_gpu_model as T
+    from multimodal_edema_prediction_amd import engine
+    from multimodal_edema_prediction_amd.graph_step import GraphedTeacherStep
+    from multimodal_edema_prediction_amd.losses_duett import DualPathologyLoss
+    from multimodal_edema_prediction_amd.optim import FusedAdamW, make_param_groups
+    dev = torch.device("cuda")
+    loss_fn = DualPathologyLoss(torch.ones(T.K), None, 0.5, 0.5, 1.0).to(dev)
+    start = T.META["teacher_batch_start"]
+    host = [T.make_batch(T.CCFG, start + 97 * i, T.B, mode="teacher") for i in range(4)]
+    host = [dict(b, pixel_values=b["pixel_values"].pin_memory()) for b in host]
+    order = [0, 1, 2, 3, 0, 2, 1, 3]
+    nxt = [1, 2, 3, 0, 1, 1, 3, 0]                  # position 4 announces batch 1 but batch 2 arrives
+    aft = [2, 3, 0, 1, 1, 3, 0, 1]
+
+    def run(staged):
+        te = T.build_teacher()
+        opt = FusedAdamW(make_param_groups(te, 8e-5), weight_decay=5e-2)
+        pool = host if staged else [engine._move_lists(b, dev) for b in host]
+        gs = GraphedTeacherStep(te, loss_fn, opt, host[0], dev, warmup=2, pipeline_cxr=True)
+        losses = [float(gs.step(pool[k], pool[n], pool[a] if staged else None)["loss"].item()) for k, n, a in zip(order, nxt, aft)]
+        return losses, {k: p.detach().clone() for k, p in te.named_parameters() if p.requires_grad}
+
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    np.testing.assert_array_equal(np.array(l1), np.array(l0))
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
