@@ -132,7 +132,18 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const float* __restrict
 #pragma unroll
     for (int rr = 0; rr < TE_ROWS; ++rr) acc[rr] = bias;
     // w3t is the TRANSPOSED weight [Hd][tt]: consecutive threads read consecutive addresses
-    for (int j = 0; j < Hd; ++j) {
+    // (eight weight loads in flight: one per iteration made the loop a chain of L2 round trips)
+    int j = 0;
+    for (; j + 8 <= Hd; j += 8) {
+        float w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = w3[(size_t)(j + u) * tt + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int rr = 0; rr < TE_ROWS; ++rr) acc[rr] += w[u] * hid[rr * Hd + j + u];
+    }
+    for (; j < Hd; ++j) {
         const float w = w3[(size_t)j * tt + c];
 #pragma unroll
         for (int rr = 0; rr < TE_ROWS; ++rr) acc[rr] += w * hid[rr * Hd + j];
