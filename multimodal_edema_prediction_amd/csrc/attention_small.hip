@@ -92,6 +92,8 @@ __device__ __forceinline__ void row_softmax(const SmallAttnParams& p, const floa
     for (int i = 0; i < nper; ++i) pj[i] *= inv;
 }
 
+constexpr int FWD_QCH = 8;     // queries per workgroup of the forward kernel (two per wave)
+
 template <int NPER>
 __global__ __launch_bounds__(256) void attn_small_fwd_kernel(const SmallAttnParams p, void* __restrict__ o, int ldo, int o_bf16,
                                                              float* __restrict__ attn_avg) {
@@ -105,7 +107,10 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(const SmallAttnPara
     const bool vec = (((p.dh | p.ldk | p.ldv) & 3) == 0) && ((((uintptr_t)kbase | (uintptr_t)vbase) & 15) == 0);
     constexpr int nper = NPER;
     float pj[NPER];
-    for (int qi = wave; qi < p.Lq; qi += 4) {
+    // a workgroup takes FWD_QCH queries (grid.y chunks): with all Lq queries in one workgroup a DuETT call (97 queries,
+    // 128 (batch, head) pairs) kept 128 CUs busy for 91 us on four waves each
+    const int qend = min(p.Lq, ((int)blockIdx.y + 1) * FWD_QCH);
+    for (int qi = blockIdx.y * FWD_QCH + wave; qi < qend; qi += 4) {
         const float* qr = p.q + (size_t)b * p.q_bs + (size_t)qi * p.ldq + h * p.dh;
         if (lane < p.dh) sq[lane] = qr[lane];
         WAVE_LDS_SYNC();
@@ -230,11 +235,12 @@ extern "C" int medp_attn_small_fwd(const float* q, int ldq, long long q_batch_st
     const size_t lds = (size_t)(4 * Lk + 4 * dh) * sizeof(float);
     const int nper = (Lk + 63) / 64;
     hipStream_t st = (hipStream_t)stream;
-    if (nper <= 1) attn_small_fwd_kernel<1><<<B * H, 256, lds, st>>>(p, o, ldo, o_bf16, attn_avg);
-    else if (nper <= 2) attn_small_fwd_kernel<2><<<B * H, 256, lds, st>>>(p, o, ldo, o_bf16, attn_avg);
-    else if (nper <= 4) attn_small_fwd_kernel<4><<<B * H, 256, lds, st>>>(p, o, ldo, o_bf16, attn_avg);
-    else if (nper <= 8) attn_small_fwd_kernel<8><<<B * H, 256, lds, st>>>(p, o, ldo, o_bf16, attn_avg);
-    else attn_small_fwd_kernel<MAXK_PER_LANE><<<B * H, 256, lds, st>>>(p, o, ldo, o_bf16, attn_avg);
+    const dim3 grid(B * H, (Lq + FWD_QCH - 1) / FWD_QCH);
+    if (nper <= 1) attn_small_fwd_kernel<1><<<grid, 256, lds, st>>>(p, o, ldo, o_bf16, attn_avg);
+    else if (nper <= 2) attn_small_fwd_kernel<2><<<grid, 256, lds, st>>>(p, o, ldo, o_bf16, attn_avg);
+    else if (nper <= 4) attn_small_fwd_kernel<4><<<grid, 256, lds, st>>>(p, o, ldo, o_bf16, attn_avg);
+    else if (nper <= 8) attn_small_fwd_kernel<8><<<grid, 256, lds, st>>>(p, o, ldo, o_bf16, attn_avg);
+    else attn_small_fwd_kernel<MAXK_PER_LANE><<<grid, 256, lds, st>>>(p, o, ldo, o_bf16, attn_avg);
     MEDP_LAUNCH_CHECK("medp_attn_small_fwd");
     return 0;
 }
