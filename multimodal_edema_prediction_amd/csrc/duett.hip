@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const float* __restrict
                                                          const float* __restrict__ sh, const float* __restrict__ w3,
                                                          const float* __restrict__ b3, const float* __restrict__ rep,
                                                          float* __restrict__ out, int B, int T, int Hd, int tt) {
-    extern __shared__ float hid[];              // [TE_ROWS][Hd]
+    extern __shared__ __attribute__((aligned(16))) float hid[];              // [Hd][TE_ROWS]
     const int rows = B * (T + 1);
     const int r0 = blockIdx.x * TE_ROWS;
     for (int idx = threadIdx.x; idx < TE_ROWS * Hd; idx += 256) {
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const float* __restrict
             const int b = row / (T + 1), t = row - b * (T + 1);
             if (t < T) h = tanhf(w0[j] * times[(size_t)b * T + t] + b0[j]) * s[j] + sh[j];
         }
-        hid[idx] = h;
+        hid[j * TE_ROWS + rr] = h;             // [Hd][TE_ROWS]: the 16 rows of one hidden unit are one 64-B broadcast read
     }
     __syncthreads();
     const int c = blockIdx.y * 256 + threadIdx.x;
@@ -139,14 +139,19 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const float* __restrict
 #pragma unroll
         for (int u = 0; u < 8; ++u) w[u] = w3[(size_t)(j + u) * tt + c];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 8; ++u) {
+            const float4* hj = (const float4*)(hid + (j + u) * TE_ROWS);
 #pragma unroll
-            for (int rr = 0; rr < TE_ROWS; ++rr) acc[rr] += w[u] * hid[rr * Hd + j + u];
+            for (int q = 0; q < TE_ROWS / 4; ++q) {
+                const float4 h4 = hj[q];
+                acc[4 * q] += w[u] * h4.x; acc[4 * q + 1] += w[u] * h4.y; acc[4 * q + 2] += w[u] * h4.z; acc[4 * q + 3] += w[u] * h4.w;
+            }
+        }
     }
     for (; j < Hd; ++j) {
         const float w = w3[(size_t)j * tt + c];
 #pragma unroll
-        for (int rr = 0; rr < TE_ROWS; ++rr) acc[rr] += w * hid[rr * Hd + j];
+        for (int rr = 0; rr < TE_ROWS; ++rr) acc[rr] += w * hid[j * TE_ROWS + rr];
     }
     const float repc = rep[c];
 #pragma unroll
