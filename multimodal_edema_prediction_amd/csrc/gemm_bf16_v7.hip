@@ -205,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v7_kernel(const MedpGemmA
     };
     auto post_ticket = [&]() {
         if (wave == 0) {
-            const int tn = NWG + 8 * (int)ticket + xcd;
+            const int tn = (int)gridDim.x + 8 * (int)ticket + xcd;      // (the grid is a multiple of 8)
             mailbox[lane] = tn < ntiles ? tn : -1;     // lane 0 holds the ticket
         }
     };
@@ -421,7 +421,9 @@ int launch_v7(const MedpGemmArgs& a, hipStream_t stream) {
     } else {
         s = g_ring_next.fetch_add(1) % RING_SLOTS;
     }
-    gemm_bf16_nt_v7_kernel<TAG><<<NWG, 512, LDS_BYTES, stream>>>(a, slots + (size_t)s * SLOT_WORDS, g_trace);
+    // MEDP_V7_WGS (a multiple of 8, <= 256): fewer resident workgroups leave CUs to the other branches of the step
+    static const int nwg = [] { const char* e = getenv("MEDP_V7_WGS"); const int v = e ? atoi(e) : NWG; return (v >= 8 && v <= NWG) ? (v & ~7) : NWG; }();
+    gemm_bf16_nt_v7_kernel<TAG><<<nwg, 512, LDS_BYTES, stream>>>(a, slots + (size_t)s * SLOT_WORDS, g_trace);
     MEDP_LAUNCH_CHECK("medp_gemm_bf16_nt(v7)");
     return 0;
 }
