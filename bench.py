@@ -253,6 +253,8 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "gemm_bf16_nt_v6_kernel<1> / gemm_bf16_nt_v7_kernel<1> (CXR-encoder block GEMMs: proj, fc2 / qkv, fc1 — one K-loop: 256x256x64 tiles, 8 waves ping-pong, 128x64 per wave; v7 = persistent over the tile list)",
                      "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                      "traffic": traffic, "launches": int(n_l.value),
+                     "note": "the matrix peak is the nominal roofline; L2 counters (profiles/r01_pmc_tcc_gemm_v6_v7.txt) show the L2 channels 79 % busy "
+                             "at 8.1 TB/s of LDS staging traffic: at 128 FLOP per staged byte the binding ceiling is ~1.05 PFLOP/s",
                      "avg_launch_us": round(ms.value * 1e3 / max(n_l.value, 1), 2),
                      "algorithmic_flops_per_launch": round(fl.value / max(n_l.value, 1), 1)},
     }
