@@ -1,16 +1,17 @@
 // v7: the v6 K-loop (256 x 256 x 64 tiles, 8 waves, two ping-pong groups, see gemm_bf16_v6.hip) made PERSISTENT for grids of
 // more than one round of workgroups with a bf16 result and no residual (qkv: 585 tiles, fc1: 780 tiles on 256 CUs).
 //
-// v6, per 256^2 tile at K = 768 (measured by switching parts off, fc1): K-loop 22 us (12 x 1.43 us at speed + ~5 us to get
-// the LDS-DMA stream going), epilogue through LDS 3.3 us, waiting for the output stores 2.9 us, erf-GELU 8 us.  Here 256
-// workgroups stay resident and walk the tile list:
-//   * the LDS-DMA stream never stops: the last two K-tiles of tile i carry K-tile 0 of tile i+1 and the W halves of its
-//     K-tile 1, the A halves of K-tile 1 follow right after the K-loop — the next K-loop starts two K-tiles deep;
+// 256 workgroups (MEDP_V7_WGS) stay resident and walk the tile list:
+//   * the LDS-DMA stream never stops: from K-tile nkt-2 on it carries K-tiles 0 and 1 of the NEXT tile (all but the last A
+//     piece, which P1 of the next K-tile 0 issues as in the steady state) — the next K-loop starts two K-tiles deep;
 //   * the epilogue needs no K buffer: bias / GELU / bf16 pack happen on the accumulator layout, the transposition to whole
 //     128-B rows goes through a 16-row bf16 patch per wave behind the K buffers, the bias slice arrives by LDS-DMA;
-//   * nothing waits for the output stores until two K-tiles into the next K-loop (vmcnt is in order: the waits in between are
-//     counted so that they end just before the stores, and there is no register-returning load anywhere in the steady state
-//     whose wait the compiler would have to place).
+//   * nothing waits for the output stores until P2 of the next K-tile 1 (vmcnt is in order: the wait that ends the epilogue is
+//     counted so that it stops just before the 16 stores of a full tile, and there is no register-returning load anywhere in the
+//     steady state whose wait the compiler would have to place).
+// What it bought (tools/trace_gemm_v7.py): the tile walk itself ~2 % on qkv / fc1 and 24 % fewer L2 misses;
+// dispatch, first-tile latency and the store drain turned out NOT to be what a round of workgroups pays for — the K-loop is
+// bound by L2 -> LDS delivery (L2 channels 79 % busy).
 // Tiles: workgroup b takes tile b first (static, so a workgroup that becomes resident late still has work that nobody else
 // does) and then draws tickets from the queue of ITS XCD (b % 8): ticket i is tile 256 + 8 i + b % 8, i.e. exactly the tile
 // the hardware dispatcher would have sent to that XCD in v6, so the band x super-column L2 locality of the v6 map holds.
