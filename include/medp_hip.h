@@ -104,6 +104,8 @@ int medp_im2col_patch(const float* pix, void* A, int B, int C, int H, int W, int
 int medp_vit_assemble(const float* patch, const float* cls, const float* pos, float* x, int B, int P, int D, void* stream);
 /* interpolate_pos_encoding, bicubic align_corners=False (modeling_dinov2.py:57-95) */
 int medp_pos_embed_bicubic(const float* pos, float* out, int src_side, int gh, int gw, int D, void* stream);
+/* its transpose (the trainable encoder): dout [1 + gh*gw, D] -> dpos [1 + src_side^2, D]; a gather, deterministic */
+int medp_pos_embed_bicubic_bwd(const float* dout, float* dpos, int src_side, int gh, int gw, int D, void* stream);
 
 /* ---- whole-module forward of the frozen CXR encoder: CXREncoder.forward (model :152-158) ---------- */
 typedef struct {

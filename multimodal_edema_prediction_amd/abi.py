@@ -77,6 +77,7 @@ SIGNATURES = {
     "medp_im2col_patch": (I, [P, P, I, I, I, I, I, I, P]),
     "medp_vit_assemble": (I, [P, P, P, P, I, I, I, P]),
     "medp_pos_embed_bicubic": (I, [P, P, I, I, I, I, P]),
+    "medp_pos_embed_bicubic_bwd": (I, [P, P, I, I, I, I, P]),
     "medp_vit_workspace_bytes": (SZ, [ctypes.POINTER(MedpVitWeights), I, I, I]),
     "medp_vit_forward": (I, [ctypes.POINTER(MedpVitWeights), P, I, I, I, P, P, P, SZ, P]),
     "medp_vit_forward_part": (I, [ctypes.POINTER(MedpVitWeights), P, I, I, I, P, P, P, SZ, I, I, P]),

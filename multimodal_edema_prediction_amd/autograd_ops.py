@@ -123,6 +123,47 @@ def linear(x, weight, bias=None, residual=None):
     return LinearFn.apply(x, weight, bias, residual)
 
 
+class LinearScaleResidualFn(torch.autograd.Function):
+    """out = (x W^T + b) * lam + res   — a Dinov2 block's `hidden + layer_scale(dense(x))` (modeling_dinov2.py:272-300) as ONE GEMM
+    with the LayerScale and the residual in its epilogue, as the frozen path runs it.  No activation-sized elementwise kernel in
+    the backward either: with G = dY^T X (the transposed GEMM on the UNSCALED dY) and s = colsum(dY),
+        dW = lam[:, None] * G      db = lam * s      dlam = rowsum(W * G) + b * s      dX = dY (lam[:, None] * W)      dres = dY
+    (dlam_n = sum_m dY[m,n] * (x W^T + b)[m,n] regrouped over k: the pre-activation is never stored)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, lam, res):
+        xb = x if x.dtype == BF16 else Fn.to_bf16(x.contiguous())
+        x2 = xb.reshape(-1, xb.shape[-1])
+        N, K = weight.shape
+        res2 = res.reshape(-1, N).contiguous()
+        y = Fn.gemm(x2, weight_bf16(weight), bias=bias.detach(), scale=lam.detach().contiguous(), residual=res2, out_dtype=F32, k=K)
+        ctx.save_for_backward(x2, weight, bias, lam)
+        ctx.x_shape = x.shape
+        return y.view(res.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, bias, lam = ctx.saved_tensors
+        N, K = weight.shape
+        dy2 = dy.reshape(-1, N).contiguous()
+        dyb = Fn.to_bf16(dy2)
+        G = Fn.gemm_tn(dyb, x2)                                  # [N, K]
+        s = Fn.colsum(dy2)
+        lam_d, w_d = lam.detach(), weight.detach()
+        dw = lam_d[:, None] * G
+        db = lam_d * s
+        dlam = (w_d * G).sum(dim=1) + bias.detach() * s
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wl_t = Fn.transpose_to_bf16((lam_d[:, None] * w_d).contiguous())         # [K, N] bf16: dX = dY (lam * W)
+            dx = Fn.gemm(dyb, wl_t, out_dtype=F32, k=N).view(ctx.x_shape)
+        return dx, dw, db, dlam, dy
+
+
+def linear_scale_residual(x, weight, bias, lam, res):
+    return LinearScaleResidualFn.apply(x, weight, bias, lam, res)
+
+
 class InProjFn(torch.autograd.Function):
     """nn.MultiheadAttention's packed input projection as ONE node:  Q = xq W[:d]^T + b[:d],  KV = xkv W[d:]^T + b[d:].
     Slicing `in_proj_weight` / `in_proj_bias` outside and feeding two Linears makes autograd rebuild the full-size gradients

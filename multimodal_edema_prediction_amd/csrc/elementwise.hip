@@ -133,6 +133,50 @@ __global__ __launch_bounds__(256) void pos_bicubic_kernel(const float* __restric
     }
 }
 
+// Backward of pos_bicubic_kernel (the trainable CXR encoder, --unfreeze_cxr): dpos[src] = sum over the destination cells whose
+// 4 x 4 footprint (with border clamping) contains src of wy * wx * dout[dst].  Written as a GATHER — one thread per (source
+// cell, 4 channels) walks the destination grid in a fixed order — so it is deterministic (no float atomics).  The footprint is a
+// product set, so the weight of (src, dst) factorises into (sum of the y taps that clamp onto src's row) x (the same in x).
+__device__ __forceinline__ float bicubic_tap_weight(int src, int dst, int s, int g) {
+    const float A = -0.75f;
+    const float sc = (float)s / (float)g;
+    const float f = (dst + 0.5f) * sc - 0.5f;
+    const int i0 = (int)floorf(f);
+    const float t = f - i0;
+    const float w[4] = {cubic2(t + 1.f, A), cubic1(t, A), cubic1(1.f - t, A), cubic2(2.f - t, A)};
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+        if (min(max(i0 - 1 + a, 0), s - 1) == src) acc += w[a];
+    return acc;
+}
+__global__ __launch_bounds__(256) void pos_bicubic_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dpos, int s, int gh,
+                                                              int gw, int D) {
+    const int d4n = D >> 2;
+    const int total = (s * s + 1) * d4n;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int d4 = i % d4n, cell = i / d4n;
+        if (cell == 0) {                                      // class position: copied in the forward
+            *(float4*)(dpos + 4 * d4) = *(const float4*)(dout + 4 * d4);
+            continue;
+        }
+        const int sy = (cell - 1) / s, sx = (cell - 1) % s;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int oy = 0; oy < gh; ++oy) {
+            const float wy = bicubic_tap_weight(sy, oy, s, gh);
+            if (wy == 0.f) continue;
+            for (int ox = 0; ox < gw; ++ox) {
+                const float wx = bicubic_tap_weight(sx, ox, s, gw);
+                if (wx == 0.f) continue;
+                const float w = wy * wx;
+                const float4 g = *(const float4*)(dout + (size_t)(1 + oy * gw + ox) * D + 4 * d4);
+                acc.x += w * g.x; acc.y += w * g.y; acc.z += w * g.z; acc.w += w * g.w;
+            }
+        }
+        *(float4*)(dpos + (size_t)cell * D + 4 * d4) = acc;
+    }
+}
+
 inline int grid_for(size_t work_items) { return (int)min((size_t)4096, max((size_t)1, (work_items + 255) / 256)); }
 
 }  // namespace
@@ -178,6 +222,13 @@ extern "C" int medp_vit_assemble(const float* patch, const float* cls, const flo
     MEDP_CHECK_ARG(patch && cls && pos && x && B > 0 && P > 0 && D % 4 == 0, "vit_assemble: bad argument");
     vit_assemble_kernel<<<grid_for((size_t)B * (P + 1) * D / 4), 256, 0, (hipStream_t)stream>>>(patch, cls, pos, x, B, P, D);
     MEDP_LAUNCH_CHECK("medp_vit_assemble");
+    return 0;
+}
+
+extern "C" int medp_pos_embed_bicubic_bwd(const float* dout, float* dpos, int src_side, int gh, int gw, int D, void* stream) {
+    MEDP_CHECK_ARG(dout && dpos && src_side > 0 && gh > 0 && gw > 0 && D > 0 && D % 4 == 0, "pos_embed_bicubic_bwd: bad argument");
+    pos_bicubic_bwd_kernel<<<grid_for((size_t)(src_side * src_side + 1) * (D / 4)), 256, 0, (hipStream_t)stream>>>(dout, dpos, src_side, gh, gw, D);
+    MEDP_LAUNCH_CHECK("medp_pos_embed_bicubic_bwd");
     return 0;
 }
 

@@ -8,7 +8,8 @@ weight-gradient GEMM, LayerNorm forward/backward, flash attention forward) plus 
 * `AttnDh64Fn`: forward = the head-dim-64 MFMA kernel (also writing the logsumexp); backward = the MFMA flash backward of
   attention_dh64_bwd.hip (dQ and dK/dV launches of one templated kernel).
 
-LayerScale and the residual adds are plain torch elementwise ops here (plumbing, autograd included).
+LayerScale and the residual add ride in the epilogue of the projection / fc2 GEMM (autograd_ops.LinearScaleResidualFn); the
+position-grid resize has its own forward / backward kernels (PosBicubicFn).
 Parity: tests/test_gpu_unfrozen_cxr.py against the oracle's autograd.
 """
 from __future__ import annotations
@@ -49,6 +50,29 @@ class PatchEmbedFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, D).contiguous()
         dw = Fn.gemm_tn(Fn.to_bf16(dy2), cols)[:, :ctx.K].reshape(ctx.wshape)
         return None, dw, Fn.colsum(dy2), None
+
+
+class PosBicubicFn(torch.autograd.Function):
+    """position_embeddings [1, 1 + s*s, D] -> [1, 1 + gh*gw, D]: bicubic resize of the patch grid (modeling_dinov2.py:57-95,
+    align_corners=False), class position copied.  Forward = the kernel the frozen path uses; backward = its transpose written as a
+    gather (deterministic).  torch's upsample_bicubic2d took 1.7 ms forward + 0.6 ms backward per step here."""
+
+    @staticmethod
+    def forward(ctx, pos, side, gh, gw):
+        D = pos.shape[-1]
+        p2 = pos.detach().reshape(-1, D).to(F32).contiguous()
+        out = torch.empty((1 + gh * gw, D), dtype=F32, device=pos.device)
+        check(lib().medp_pos_embed_bicubic(ptr(p2), ptr(out), side, gh, gw, D, stream()), "pos_embed_bicubic")
+        ctx.dims = (side, gh, gw, D, pos.shape)
+        return out.view(1, 1 + gh * gw, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        side, gh, gw, D, shape = ctx.dims
+        d2 = dout.reshape(-1, D).contiguous()
+        dpos = torch.empty((1 + side * side, D), dtype=F32, device=dout.device)
+        check(lib().medp_pos_embed_bicubic_bwd(ptr(d2), ptr(dpos), side, gh, gw, D, stream()), "pos_embed_bicubic_bwd")
+        return dpos.view(shape), None, None, None
 
 
 class AttnDh64Fn(torch.autograd.Function):
@@ -93,12 +117,8 @@ def forward_training(backbone, pixel_values: torch.Tensor) -> torch.Tensor:
     pos = sd["embeddings.position_embeddings"].reshape(1, -1, D)
     side = c.image_size // c.patch_size
     if not (gh == side and gw == side):
-        # modeling_dinov2.py:57-95: bicubic resize of the stored patch grid (align_corners=False).  The frozen path has its own
-        # kernel for this (medp_pos_embed_bicubic); the trainable path needs the transpose as well and takes torch's
-        # interpolate with its autograd — 257 x 768 values once per step, plumbing next to the encoder's 92 GFLOP/sample backward
-        grid = pos[:, 1:].reshape(1, side, side, D).permute(0, 3, 1, 2)
-        grid = torch.nn.functional.interpolate(grid, size=(gh, gw), mode="bicubic", align_corners=False)
-        pos = torch.cat([pos[:, :1], grid.permute(0, 2, 3, 1).reshape(1, gh * gw, D)], dim=1)
+        # modeling_dinov2.py:57-95: bicubic resize of the stored patch grid (align_corners=False)
+        pos = PosBicubicFn.apply(sd["embeddings.position_embeddings"], side, gh, gw)
     x = torch.cat([cls, patch], dim=1) + pos
     S = x.shape[1]
     x = x.reshape(B * S, D)
@@ -109,11 +129,10 @@ def forward_training(backbone, pixel_values: torch.Tensor) -> torch.Tensor:
         bqkv = torch.cat([sd[p + f"attention.attention.{n}.bias"] for n in ("query", "key", "value")], 0)
         qkv = A.linear(h, wqkv, bqkv)
         att = AttnDh64Fn.apply(qkv, B, S, H)
-        y = A.linear(att, sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"])
-        x = x + y * sd[p + "layer_scale1.lambda1"]
+        x = A.linear_scale_residual(att, sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"],
+                                    sd[p + "layer_scale1.lambda1"], x)
         h = A.layer_norm(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"], c.layer_norm_eps)
         f = A.gelu_dropout(A.linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]), 0.0, 0, 0)
-        y = A.linear(f, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
-        x = x + y * sd[p + "layer_scale2.lambda1"]
+        x = A.linear_scale_residual(f, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"], sd[p + "layer_scale2.lambda1"], x)
     x = A.layer_norm(x, sd["layernorm.weight"], sd["layernorm.bias"], c.layer_norm_eps)
     return x.view(B, S, D)
