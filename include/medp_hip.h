@@ -98,6 +98,9 @@ int medp_scalenorm_bwd(const float* dy, int lddy, const float* x, int ldx, const
 int medp_cast_f32_bf16(const float* x, int ldx, void* y, int ldy, int rows, int cols, void* stream);
 int medp_transpose_to_bf16(const void* x, int x_is_bf16, int ldx, void* y, int ldy, int rows, int cols, void* stream);
 int medp_gelu_bwd(const float* dy, const float* pre, float* dx, long long n, void* stream);
+/* bf16 forms (trainable CXR encoder, fused blocks): out = gelu(pre); dx = dy * gelu'(pre); all three bf16, n % 8 == 0 */
+int medp_gelu_bf16_fwd(const void* pre, void* out, long long n, void* stream);
+int medp_gelu_bf16_bwd(const void* dy, const void* pre, void* dx, long long n, void* stream);
 /* Dinov2PatchEmbeddings conv14/s14 as im2col (modeling_dinov2.py:139,148) */
 int medp_im2col_patch(const float* pix, void* A, int B, int C, int H, int W, int patch, int kpad, void* stream);
 /* cls token + position embeddings (modeling_dinov2.py:108-112) */

@@ -74,6 +74,8 @@ SIGNATURES = {
     "medp_cast_f32_bf16": (I, [P, I, P, I, I, I, P]),
     "medp_transpose_to_bf16": (I, [P, I, I, P, I, I, I, P]),
     "medp_gelu_bwd": (I, [P, P, P, LL, P]),
+    "medp_gelu_bf16_fwd": (I, [P, P, LL, P]),
+    "medp_gelu_bf16_bwd": (I, [P, P, P, LL, P]),
     "medp_im2col_patch": (I, [P, P, I, I, I, I, I, I, P]),
     "medp_vit_assemble": (I, [P, P, P, P, I, I, I, P]),
     "medp_pos_embed_bicubic": (I, [P, P, I, I, I, I, P]),

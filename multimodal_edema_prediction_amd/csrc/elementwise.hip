@@ -51,6 +51,38 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__
     }
 }
 
+// bf16 forms for the fused blocks of the trainable CXR encoder (cxr_train.py): the fc1 pre-activation is kept in bf16
+// (it is the only copy the backward needs), f = gelu(pre) feeds fc2 in bf16, and the backward writes d(pre) in bf16 — the operand
+// of both fc1 gradient GEMMs.  8 values (16 B) per thread; arithmetic in fp32.
+__global__ __launch_bounds__(256) void gelu_bf16_fwd_kernel(const bf16_t* __restrict__ pre, bf16_t* __restrict__ out, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const uint4 p = *(const uint4*)(pre + i * 8);
+        const uint32_t w[4] = {p.x, p.y, p.z, p.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x2 g = gelu_erf2((f32x2){__uint_as_float(w[k] << 16), __uint_as_float(w[k] & 0xffff0000u)});
+            o[k] = pack_bf2(g[0], g[1]);
+        }
+        *(uint4*)(out + i * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+__global__ __launch_bounds__(256) void gelu_bf16_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ pre,
+                                                            bf16_t* __restrict__ dx, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const uint4 g = *(const uint4*)(dy + i * 8), p = *(const uint4*)(pre + i * 8);
+        const uint32_t gw[4] = {g.x, g.y, g.z, g.w}, pw[4] = {p.x, p.y, p.z, p.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a = __uint_as_float(gw[k] << 16) * gelu_erf_grad(__uint_as_float(pw[k] << 16));
+            const float b = __uint_as_float(gw[k] & 0xffff0000u) * gelu_erf_grad(__uint_as_float(pw[k] & 0xffff0000u));
+            o[k] = pack_bf2(a, b);
+        }
+        *(uint4*)(dx + i * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // ---- ViT front end ---------------------------------------------------------------------------------------
 // im2col for the 14x14 / stride-14 patch embedding: A[b*P + py*gw + px][c*196 + i*14 + j] = pix[b][c][py*14+i][px*14+j]
 // written as bf16 with the row padded to `kpad` (zeros) so the GEMM sees 16-B aligned rows.
@@ -204,6 +236,21 @@ extern "C" int medp_gelu_bwd(const float* dy, const float* pre, float* dx, long 
     MEDP_CHECK_ARG(dy && pre && dx && n > 0 && n % 4 == 0, "gelu_bwd: bad argument (n must be a multiple of 4)");
     gelu_bwd_kernel<<<grid_for((size_t)n / 4), 256, 0, (hipStream_t)stream>>>(dy, pre, dx, (size_t)n);
     MEDP_LAUNCH_CHECK("medp_gelu_bwd");
+    return 0;
+}
+
+extern "C" int medp_gelu_bf16_fwd(const void* pre, void* out, long long n, void* stream) {
+    MEDP_CHECK_ARG(pre && out && n > 0 && n % 8 == 0, "gelu_bf16_fwd: bad argument (n must be a multiple of 8)");
+    gelu_bf16_fwd_kernel<<<grid_for((size_t)n / 8), 256, 0, (hipStream_t)stream>>>((const bf16_t*)pre, (bf16_t*)out, (size_t)n / 8);
+    MEDP_LAUNCH_CHECK("medp_gelu_bf16_fwd");
+    return 0;
+}
+
+extern "C" int medp_gelu_bf16_bwd(const void* dy, const void* pre, void* dx, long long n, void* stream) {
+    MEDP_CHECK_ARG(dy && pre && dx && n > 0 && n % 8 == 0, "gelu_bf16_bwd: bad argument (n must be a multiple of 8)");
+    gelu_bf16_bwd_kernel<<<grid_for((size_t)n / 8), 256, 0, (hipStream_t)stream>>>((const bf16_t*)dy, (const bf16_t*)pre, (bf16_t*)dx,
+                                                                                  (size_t)n / 8);
+    MEDP_LAUNCH_CHECK("medp_gelu_bf16_bwd");
     return 0;
 }
 

@@ -1,15 +1,16 @@
 """Trainable form of the CXR encoder (`--unfreeze_cxr`, run.py:184-187; SURVEY.md §8(f1), second half).
 
-The frozen encoder is one C call (`medp_vit_forward`); when any of its parameters requires a gradient the forward is
-composed here from the autograd nodes of `autograd_ops` instead — the same HIP kernels (bf16 MFMA GEMMs incl. the transposed
-weight-gradient GEMM, LayerNorm forward/backward, flash attention forward) plus two nodes of its own:
+The frozen encoder is one C call (`medp_vit_forward`); when any of its parameters requires a gradient the forward is composed
+here from autograd nodes over the same HIP kernels:
 
 * `PatchEmbedFn`: conv14/stride14 as im2col + GEMM; backward is the weight-gradient GEMM on the saved bf16 columns;
-* `AttnDh64Fn`: forward = the head-dim-64 MFMA kernel (also writing the logsumexp); backward = the MFMA flash backward of
-  attention_dh64_bwd.hip (dQ and dK/dV launches of one templated kernel).
+* `PosBicubicFn`: the position-grid resize, forward and (gather-form, deterministic) backward kernels;
+* `AttnHalfFn` / `MlpHalfFn`: the two halves of a block, each ONE node with a hand-chained backward — LayerNorm, qkv GEMM, flash
+  attention (forward with logsumexp / MFMA flash backward of attention_dh64_bwd.hip) and the fc1 pre-activation all hand bf16
+  to the next kernel, LayerScale + residual ride in the epilogue of the projection / fc2 GEMM, and their gradients (dW, db,
+  dlambda) come from the unscaled transposed GEMM, so no activation-sized elementwise or cast kernel runs between the stages;
+  only the residual stream is fp32.  (`AttnDh64Fn` is the stand-alone attention node of the first, op-by-op composition.)
 
-LayerScale and the residual add ride in the epilogue of the projection / fc2 GEMM (autograd_ops.LinearScaleResidualFn); the
-position-grid resize has its own forward / backward kernels (PosBicubicFn).
 Parity: tests/test_gpu_unfrozen_cxr.py against the oracle's autograd.
 """
 from __future__ import annotations
@@ -102,6 +103,90 @@ class AttnDh64Fn(torch.autograd.Function):
         return Fn.attn_dh64_bwd(do, qkv16, o, lse, B, S, H, 0.125), None, None, None
 
 
+def _ls_linear_backward(dy2, dyb, x16, weight, bias, lam, need_dx=True):
+    """Gradients of out = (x W^T + b) * lam + res given dY (fp32) and its bf16 copy: (dX fp32 | None, dW, db, dlam) — no
+    activation-sized elementwise kernel (see autograd_ops.LinearScaleResidualFn)."""
+    G = Fn.gemm_tn(dyb, x16)
+    s = Fn.colsum(dy2)
+    lam_d, w_d = lam.detach(), weight.detach()
+    dx = Fn.gemm(dyb, Fn.transpose_to_bf16((lam_d[:, None] * w_d).contiguous()), out_dtype=F32, k=weight.shape[0]) if need_dx else None
+    return dx, lam_d[:, None] * G, lam_d * s, (w_d * G).sum(dim=1) + bias.detach() * s
+
+
+class AttnHalfFn(torch.autograd.Function):
+    """x + lam * (dense(attention(qkv(LayerNorm(x)))) + b): the attention half of a Dinov2 block (modeling_dinov2.py:342-381) as ONE
+    autograd node.  Inside, every GEMM operand is produced in bf16 by the kernel before it (LayerNorm -> bf16, qkv GEMM -> bf16,
+    attention -> bf16) and the backward is chained by hand, so no fp32 copy of qkv / attention output exists and no cast kernel runs
+    between the stages; only the residual stream x is fp32.  The three projection weights stay separate parameters."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, wq, wk, wv, bq, bk, bv, wo, bo, lam, eps, B, S, H):
+        x = x.contiguous()
+        h16, mean, rstd = Fn.layernorm(x, ln_w.detach(), ln_b.detach(), eps, out_dtype=BF16, save_stats=True)
+        wqkv = torch.cat([wq.detach(), wk.detach(), wv.detach()], 0)
+        bqkv = torch.cat([bq.detach(), bk.detach(), bv.detach()], 0)
+        qkv16 = Fn.gemm(h16, Fn.to_bf16(wqkv), bias=bqkv, out_dtype=BF16)
+        o16, lse = Fn.attn_dh64_lse(qkv16, B, S, H, 0.125)
+        out = Fn.gemm(o16, A.weight_bf16(wo), bias=bo.detach(), scale=lam.detach().contiguous(), residual=x, out_dtype=F32)
+        ctx.save_for_backward(x, mean, rstd, h16, qkv16, o16, lse, ln_w, wqkv, wo, bo, lam)
+        ctx.dims = (B, S, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, h16, qkv16, o16, lse, ln_w, wqkv, wo, bo, lam = ctx.saved_tensors
+        B, S, H = ctx.dims
+        D = H * 64
+        dy2 = dy.contiguous()
+        dyb = Fn.to_bf16(dy2)
+        do, dwo, dbo, dlam = _ls_linear_backward(dy2, dyb, o16, wo, bo, lam)
+        dqkv = Fn.attn_dh64_bwd(do, qkv16, o16, lse, B, S, H, 0.125)                  # fp32 [M, 3D]
+        dqkvb = Fn.to_bf16(dqkv)
+        dwqkv = Fn.gemm_tn(dqkvb, h16)
+        dbqkv = Fn.colsum(dqkv)
+        dh = Fn.gemm(dqkvb, Fn.transpose_to_bf16(wqkv), out_dtype=F32, k=3 * D)
+        dx_ln, dlnw, dlnb = Fn.layernorm_bwd(dh, x, ln_w.detach(), mean, rstd)
+        dx = dy2 + dx_ln
+        return (dx, dlnw, dlnb, dwqkv[:D], dwqkv[D:2 * D], dwqkv[2 * D:], dbqkv[:D], dbqkv[D:2 * D], dbqkv[2 * D:], dwo, dbo, dlam,
+                None, None, None, None)
+
+
+class MlpHalfFn(torch.autograd.Function):
+    """x + lam * (fc2(gelu(fc1(LayerNorm(x)))) + b2): the MLP half of a Dinov2 block as one autograd node.  fc1 writes its
+    pre-activation in bf16 (the only copy kept for the backward), gelu runs bf16 -> bf16, fc2 carries LayerScale + residual in its
+    epilogue; backward: d(gelu) in bf16 straight into both fc1 gradient GEMMs, db1 from the transposed GEMM against a ones column."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, lam, eps):
+        x = x.contiguous()
+        h16, mean, rstd = Fn.layernorm(x, ln_w.detach(), ln_b.detach(), eps, out_dtype=BF16, save_stats=True)
+        pre16 = Fn.gemm(h16, A.weight_bf16(w1), bias=b1.detach(), out_dtype=BF16)
+        f16 = torch.empty_like(pre16)
+        check(lib().medp_gelu_bf16_fwd(ptr(pre16), ptr(f16), pre16.numel(), stream()), "gelu_bf16_fwd")
+        out = Fn.gemm(f16, A.weight_bf16(w2), bias=b2.detach(), scale=lam.detach().contiguous(), residual=x, out_dtype=F32)
+        ctx.save_for_backward(x, mean, rstd, h16, pre16, f16, ln_w, w1, w2, b2, lam)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, h16, pre16, f16, ln_w, w1, w2, b2, lam = ctx.saved_tensors
+        dy2 = dy.contiguous()
+        dyb = Fn.to_bf16(dy2)
+        G2 = Fn.gemm_tn(dyb, f16)
+        s = Fn.colsum(dy2)
+        lam_d, w2_d = lam.detach(), w2.detach()
+        dw2, db2, dlam = lam_d[:, None] * G2, lam_d * s, (w2_d * G2).sum(dim=1) + b2.detach() * s
+        df16 = Fn.gemm(dyb, Fn.transpose_to_bf16((lam_d[:, None] * w2_d).contiguous()), out_dtype=BF16, k=w2.shape[0])
+        dpre16 = torch.empty_like(df16)
+        check(lib().medp_gelu_bf16_bwd(ptr(df16), ptr(pre16), ptr(dpre16), df16.numel(), stream()), "gelu_bf16_bwd")
+        dw1 = Fn.gemm_tn(dpre16, h16)
+        ones = torch.ones((dpre16.shape[0], 8), dtype=BF16, device=dy.device)
+        db1 = Fn.gemm_tn(dpre16, ones)[:, 0].contiguous()                       # column sums of a bf16 matrix, fp32 accumulation
+        dh = Fn.gemm(dpre16, A.weight_t_bf16(w1), out_dtype=F32, k=w1.shape[0])
+        dx_ln, dlnw, dlnb = Fn.layernorm_bwd(dh, x, ln_w.detach(), mean, rstd)
+        return dy2 + dx_ln, dlnw, dlnb, dw1, db1, dw2, db2, dlam, None
+
+
 def forward_training(backbone, pixel_values: torch.Tensor) -> torch.Tensor:
     """Dinov2Model.forward(...).last_hidden_state with autograd through every parameter: [B, P+1, hidden] fp32."""
     c = backbone.cfg
@@ -124,15 +209,12 @@ def forward_training(backbone, pixel_values: torch.Tensor) -> torch.Tensor:
     x = x.reshape(B * S, D)
     for l in range(c.num_hidden_layers):
         p = f"encoder.layer.{l}."
-        h = A.layer_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], c.layer_norm_eps)
-        wqkv = torch.cat([sd[p + f"attention.attention.{n}.weight"] for n in ("query", "key", "value")], 0)
-        bqkv = torch.cat([sd[p + f"attention.attention.{n}.bias"] for n in ("query", "key", "value")], 0)
-        qkv = A.linear(h, wqkv, bqkv)
-        att = AttnDh64Fn.apply(qkv, B, S, H)
-        x = A.linear_scale_residual(att, sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"],
-                                    sd[p + "layer_scale1.lambda1"], x)
-        h = A.layer_norm(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"], c.layer_norm_eps)
-        f = A.gelu_dropout(A.linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]), 0.0, 0, 0)
-        x = A.linear_scale_residual(f, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"], sd[p + "layer_scale2.lambda1"], x)
+        a = p + "attention.attention."
+        x = AttnHalfFn.apply(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], sd[a + "query.weight"], sd[a + "key.weight"],
+                             sd[a + "value.weight"], sd[a + "query.bias"], sd[a + "key.bias"], sd[a + "value.bias"],
+                             sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"],
+                             sd[p + "layer_scale1.lambda1"], c.layer_norm_eps, B, S, H)
+        x = MlpHalfFn.apply(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"], sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"],
+                            sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"], sd[p + "layer_scale2.lambda1"], c.layer_norm_eps)
     x = A.layer_norm(x, sd["layernorm.weight"], sd["layernorm.bias"], c.layer_norm_eps)
     return x.view(B, S, D)
