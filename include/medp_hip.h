@@ -46,10 +46,14 @@ int medp_gemm_bf16_nt(const void* A, const void* W, void* C, int M, int N, int K
 size_t medp_gemm_tn_workspace_bytes(int M, int N, int K);
 int medp_gemm_bf16_tn(const void* dY, const void* X, float* C, int M, int N, int K, int lddy, int ldx, float* workspace, void* stream);
 
-/* Live timing of the step's dominant kernel (the CXR-encoder block GEMMs launched by medp_vit_forward): when enabled,
- * HIP events bracket every such launch on its own stream; collect() synchronises the events (host side) and returns the
- * summed kernel time, the launch count and the algorithmic FLOPs (2*M*N*K per launch).  Used by bench.py's roofline leg. */
-int medp_gemm_profile_enable(int on);
+/* Live timing of the step's dominant kernel (the CXR-encoder block GEMMs launched by medp_vit_forward), bench.py's roofline
+ * leg.  mode 1: HIP events bracket every such launch on its own stream (eager launches).  mode 2: every such launch issued
+ * or CAPTURED while the mode is on carries an in-kernel launch clock (first workgroup in / last workgroup out stamp the
+ * 100-MHz wall clock into a private device slot), so the begin / end of the LAST execution of each launch can be read after
+ * replaying a hipGraph - the in-step figure.  mode 0 stops arming and keeps what was gathered.  collect() (device
+ * synchronised by the caller in mode 2) returns the summed kernel time, the launch count and the algorithmic FLOPs
+ * (2*M*N*K per launch). */
+int medp_gemm_profile_enable(int mode);
 int medp_gemm_profile_collect(double* host_total_ms, long long* host_n_launches, double* host_total_flops);
 
 /* ---- attention ---------------------------------------------------------------------------------- */
@@ -175,6 +179,27 @@ typedef struct {
     const MedpEncoderWeights* event_enc;   /* HOST arrays of n_layers entries */
     const MedpEncoderWeights* time_enc;
 } MedpDuettWeights;
+
+/* ---- device-side batch assembly -------------------------------------------------------------------------
+ * medp_feats_to_input replaces the host loop of Model.feats_to_input (duett/duett.py:159-187): sample b is a ragged series
+ * [T_b, 2V] (values | observation counts) with bin times [T_b], given EITHER by device pointer tables (ts_ptrs / time_ptrs,
+ * [B] device arrays of device pointers) OR as rows of one stacked buffer (ts_base + b*ts_stride, time_base + b*time_stride,
+ * strides in elements); lengths [B] int32 device array of T_b (NULL: every sample has T_uniform steps).
+ * Output: xs_ts [B, Tpad, 2V+1] (last max_len steps, zero mask column appended, zero padded; Tpad = the longest kept length,
+ * computed by the caller from the shapes), xs_times [B, Tpad], xs_static [B, Ds].
+ * Training augmentation (duett.py:169-175,184-185): values += aug_noise * N(0,1) * count; timesteps dropped with probability
+ * aug_mask (row := 0, mask column := 1); static += aug_noise * N(0,1); draws from the counter-based hash (seed, stream_id,
+ * element, RNG epoch) - with both rates 0 the result is bit-exact. */
+int medp_feats_to_input(const float* const* ts_ptrs, const float* ts_base, long long ts_stride, const float* const* time_ptrs,
+                        const float* time_base, long long time_stride, const int* lengths, int T_uniform, const float* static_in,
+                        float* xs_ts, float* xs_times, float* xs_static, int B, int V, int Ds, int max_len, int Tpad, float aug_noise,
+                        float aug_mask, unsigned seed, unsigned stream_id, void* stream);
+/* Masking half of Model.pretrain_prep_batch (duett.py:189-237) for pretrain_masked_steps == 1: mask_t [B] int32 = masked
+ * timestep, event_idx [B] int32 = masked variable (NULL: predict_events off), keep [B,V] uint8 = the variable-dropout draw
+ * (NULL: pretrain_dropout 0) - the HOST draws them (numpy Generator, reference order).  Writes the clipped input
+ * [B,T,2V+1], y_ts / y_masks [B,V], y_events / y_events_mask [B,T]. */
+int medp_ssl_mask_batch(const float* xs_ts, const int* mask_t, const int* event_idx, const unsigned char* keep, float* clipped,
+                        float* y_ts, float* y_masks, float* y_events, float* y_events_mask, int B, int T, int V, void* stream);
 
 size_t medp_duett_workspace_bytes(const MedpDuettWeights* host_w, int B, int T);
 /* xs_static [B,Ds], xs_ts [B,T,2V+1], xs_times [B,T] fp32 (outputs of feats_to_input) -> tokens [B, T+1, E*(V+1)];

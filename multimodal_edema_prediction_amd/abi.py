@@ -83,6 +83,8 @@ SIGNATURES = {
     "medp_vit_workspace_bytes": (SZ, [ctypes.POINTER(MedpVitWeights), I, I, I]),
     "medp_vit_forward": (I, [ctypes.POINTER(MedpVitWeights), P, I, I, I, P, P, P, SZ, P]),
     "medp_vit_forward_part": (I, [ctypes.POINTER(MedpVitWeights), P, I, I, I, P, P, P, SZ, I, I, P]),
+    "medp_feats_to_input": (I, [P, P, LL, P, P, LL, P, I, P, P, P, P, I, I, I, I, I, F, F, U, U, P]),
+    "medp_ssl_mask_batch": (I, [P, P, P, P, P, P, P, P, P, I, I, I, P]),
     "medp_duett_workspace_bytes": (SZ, [ctypes.POINTER(MedpDuettWeights), I, I]),
     "medp_duett_encode": (I, [ctypes.POINTER(MedpDuettWeights), P, P, P, I, I, P, P, P, P, SZ, P]),
     "medp_gelu_dropout_fwd": (I, [P, P, LL, F, U, U, P]),

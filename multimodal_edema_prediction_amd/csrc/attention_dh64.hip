@@ -114,8 +114,11 @@ __device__ __forceinline__ void key_block(WaveState<NQW>& w, const char* sK, con
         // Plain scalar fma / exp / add on purpose.  Written as packed pairs (v_pk_fma_f32 on the MFMA results, v_pk_add_f32
         // on the fresh v_exp_f32 results) the same arithmetic was NOT bit-stable once other kernels shared the SIMD: about
         // 1 % of launches returned a 16-query subtile off by ~1e-2 under the two-stream training step, none when the
-        // kernel ran alone (some issue-timing hazard around packed f32 consumers; the scalar form costs no time).
-        // tools/debug_determinism7.py / tests/test_gpu_bit_stability.py are the screens for it.
+        // kernel ran alone.  The ISA of both builds was audited (DESIGN.md "Bit stability", tools/isa_hazard_audit.py): the
+        // LDS-DMA wait precedes every staging barrier in BOTH, every software-managed dependency distance is the same in both
+        // except the packed build's own pairs (MFMA -> v_pk_fma 31 wait states, v_pk_fma -> v_exp 4), all beyond the ISA's
+        // stated minima — so the cause is not a missing wait the source can add; the scalar form stays (it costs no time).
+        // tests/test_gpu_bit_stability.py is the screen for it.
         float ls = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
@@ -202,7 +205,8 @@ __device__ __forceinline__ void wave_body(const AttnParams& p, char* sK, char* s
             glds16(ok ? p.k + grow * p.ldk + h * 64 + c * 8 : zero, sK + (i * 256 + wave * 64) * 16);
             glds16(ok ? p.v + grow * p.ldv + h * 64 + c * 8 : zero, sV + (i * 256 + wave * 64) * 16);
         }
-        __syncthreads();               // hipcc waits vmcnt(0) for the LDS-DMA before the barrier
+        MEDP_WAIT_LDS_DMA();           // the chunk's LDS-DMA has landed ...
+        __syncthreads();               // ... before any wave reads it
         if constexpr (NQW > 0) {
             const int nfull = nkeys >> 6;
             for (int kb = 0; kb < nfull; ++kb) key_block<NQW, false>(w, sK, sV, kb, 64, p.scale_log2e, fr, kq);
@@ -264,11 +268,9 @@ static int attn_fwd_launch(const void* q, const void* k, const void* v, void* o,
     p.crows = min(KC, (S + 31) / 32 * 32);
     constexpr int LDS_MAX = 2 * KC * 128;
     const int LDS = 2 * p.crows * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
+    MEDP_ONCE_PER_DEVICE({
         hipFuncSetAttribute((const void*)attn_fwd_dh64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
-        attr_set = true;
-    }
+    });
     // floor(ntile/8) workgroups: every wave gets 1..3 subtiles (ntile < 8*(nb+1) <= 12*nb)
     const int ntile = (S + 15) / 16;
     dim3 grid(ntile >= 8 ? ntile / 8 : 1, H, B);

@@ -109,7 +109,8 @@ __device__ __forceinline__ void wave_body(const BwdParams& p, char* smem, int ow
                 sD[i] = ok ? p.dsum[st0 + c0 + i] : 0.f;
             }
         }
-        __syncthreads();               // waits vmcnt(0) / lgkmcnt(0) before the barrier
+        MEDP_WAIT_LDS_DMA();
+        __syncthreads();               // LDS-DMA landed (explicit wait above) before any wave reads the chunk
         if constexpr (NWW > 0) {
             const int nblk = (nrows + 63) >> 6;
             for (int kb = 0; kb < nblk; ++kb) {
@@ -274,12 +275,10 @@ extern "C" int medp_attn_bwd_dh64(const void* q, const void* k, const void* v, i
     p.crows = min(KC, (S + 31) / 32 * 32);
     constexpr int LDS_MAX = 2 * KC * 128 + 2 * KC * 4;
     const int LDS = 2 * p.crows * 128 + 2 * p.crows * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    MEDP_ONCE_PER_DEVICE({
         hipFuncSetAttribute((const void*)attn_bwd_dh64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
         hipFuncSetAttribute((const void*)attn_bwd_dh64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
-        attr_set = true;
-    }
+    });
     const int ntile = (S + 15) / 16;
     dim3 grid((ntile + 7) / 8, H, B);              // every wave owns 0..2 subtiles
     attn_bwd_dh64_kernel<false><<<grid, 256, LDS, (hipStream_t)stream>>>(p);

@@ -256,15 +256,13 @@ extern "C" int medp_attn_small_bwd(const float* dout, int lddo, const float* q, 
     MEDP_CHECK_ARG(dout && dq && dk && dv, "attn_small_bwd: null gradient buffer");
     const size_t lds = (size_t)(2 * QCH * Lk + 2 * QCH * dh) * sizeof(float);
     MEDP_CHECK_ARG(lds <= 160 * 1024, "attn_small_bwd: Lk too large for LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
+    MEDP_ONCE_PER_DEVICE({
         hipFuncSetAttribute((const void*)attn_small_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute((const void*)attn_small_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute((const void*)attn_small_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute((const void*)attn_small_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute((const void*)attn_small_bwd_kernel<MAXK_PER_LANE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    });
     const int nper = (Lk + 63) / 64;
     hipStream_t st = (hipStream_t)stream;
 #define MEDP_BWD_ARGS p, dout, lddo, dq, lddq, dk, lddk, dv, lddv, dkv_batch_stride

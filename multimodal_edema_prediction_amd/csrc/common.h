@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <mutex>
+
 typedef uint16_t bf16_t;                                            // raw bf16 bits
 typedef __attribute__((ext_vector_type(8))) short bf16x8;           // 8 bf16 = one MFMA A/B fragment (4 VGPRs)
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
@@ -30,6 +32,20 @@ void medp_set_error(const char* fmt, ...);
             return (int)e__;                                                            \
         }                                                                               \
     } while (0)
+// Run `body` once per HIP device (thread-safe: the autograd thread and the caller's thread may race to the first launch;
+// hipFuncSetAttribute applies to the CURRENT device only).  `body` is a brace block.
+#define MEDP_MAX_DEVICES 16
+#define MEDP_ONCE_PER_DEVICE(...)                                              \
+    do {                                                                       \
+        static std::once_flag once__[MEDP_MAX_DEVICES];                        \
+        int dev__ = 0;                                                         \
+        (void)hipGetDevice(&dev__);                                            \
+        std::call_once(once__[dev__ % MEDP_MAX_DEVICES], [&]() __VA_ARGS__);   \
+    } while (0)
+// LDS-DMA (`global_load_lds`) is tracked by vmcnt: the data must have landed before the workgroup barrier that publishes
+// the tile.  hipcc emits this wait in front of __syncthreads() today (checked in the ISA, tools/isa_hazard_audit.py); it is
+// written out so that the guarantee does not hang on the compiler version.
+#define MEDP_WAIT_LDS_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define MEDP_TRY(expr)               \
     do {                             \
         int rc__ = (expr);           \

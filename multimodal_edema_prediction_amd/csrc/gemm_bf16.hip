@@ -22,7 +22,7 @@
 #include <vector>
 
 #include "common.h"
-#include "gemm_v4.h"
+#include "gemm_variants.h"
 #include "medp_hip.h"
 
 namespace {
@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const GemmParams p
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     stage(0, 0);
-    __syncthreads();   // hipcc waits vmcnt(0) for the LDS-DMA before the barrier
+    MEDP_WAIT_LDS_DMA();
+    __syncthreads();   // tile 0 landed (explicit wait) before any wave reads it
 
     const int a_row0 = wr * (BM / 2) + fr, b_row0 = wc * (BN / 2) + fr;
     const int sw = fr & 7;   // (row & 7): every row base is a multiple of 16
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const GemmParams p
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
         }
+        MEDP_WAIT_LDS_DMA();   // tile kt+1 (issued at the top of this iteration) has landed
         __syncthreads();
     }
 
@@ -285,11 +287,9 @@ template <int TAG>
 int launch_v2(const GemmParams& p, hipStream_t stream) {
     const int tiles = ((p.M + 255) / 256) * ((p.N + 127) / 128);
     constexpr int LDS = 3 * (256 + 128) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
+    MEDP_ONCE_PER_DEVICE({
         hipFuncSetAttribute((const void*)gemm_bf16_nt_v2_kernel<TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    });
     gemm_bf16_nt_v2_kernel<TAG><<<tiles, 512, LDS, stream>>>(p);
     MEDP_LAUNCH_CHECK("medp_gemm_bf16_nt(v2)");
     return 0;
@@ -451,11 +451,9 @@ template <int TAG>
 int launch_v3(const GemmParams& p, hipStream_t stream) {
     const int tiles = ((p.M + 255) / 256) * ((p.N + 127) / 128);
     constexpr int LDS = 3 * (256 + 128) * 64;
-    static bool attr_set = false;
-    if (!attr_set) {
+    MEDP_ONCE_PER_DEVICE({
         hipFuncSetAttribute((const void*)gemm_bf16_nt_v3_kernel<TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    });
     gemm_bf16_nt_v3_kernel<TAG><<<tiles, 256, LDS, stream>>>(p);
     MEDP_LAUNCH_CHECK("medp_gemm_bf16_nt(v3)");
     return 0;
@@ -465,11 +463,9 @@ template <int BM, int BN, int TAG>
 int launch(const GemmParams& p, hipStream_t stream) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     constexpr int LDS = 2 * (BM + BN) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
+    MEDP_ONCE_PER_DEVICE({
         hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<BM, BN, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    });
     gemm_bf16_nt_kernel<BM, BN, TAG><<<tiles, 256, LDS, stream>>>(p);
     MEDP_LAUNCH_CHECK("medp_gemm_bf16_nt");
     return 0;
@@ -477,28 +473,71 @@ int launch(const GemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
-// ---- live timing of the dominant kernel (bench.py roofline leg): HIP events around every tag-1 launch, recorded on
-// the stream the kernel is launched on; collected (with a host-side event sync) after the timed region -----------------
+// ---- live timing of the dominant kernel (bench.py roofline leg) ----------------------------------------------------------
+// mode 1: HIP events around every tag-1 launch, recorded on the stream the kernel is launched on (eager launches only:
+//         events cannot be read back out of a replayed hipGraph on this ROCm);
+// mode 2: an in-kernel launch clock — every tag-1 launch issued (or CAPTURED) while the mode is on gets a private slot of
+//         four u64 in device memory; the first workgroup in and the last workgroup out stamp the 100-MHz wall clock, so a
+//         slot always holds the begin / end of the LAST execution of its launch, replays of a captured graph included.
 namespace {
 struct GemmProfile {
-    bool on = false;
-    std::vector<hipEvent_t> ev;      // pairs (start, stop)
+    int mode = 0;
+    std::vector<hipEvent_t> ev;      // mode 1: pairs (start, stop)
     size_t used = 0;
     double flops = 0.0;
+    unsigned long long* slots = nullptr;     // mode 2: device [MAX_SLOTS][4]
+    std::vector<double> slot_flops;
+    int slot_dev = -1;
 };
+constexpr size_t MAX_PROF_SLOTS = 4096;
 GemmProfile g_prof;
 }  // namespace
 
-extern "C" int medp_gemm_profile_enable(int on) {
-    g_prof.on = on != 0;
-    g_prof.used = 0;
-    g_prof.flops = 0.0;
+extern "C" int medp_gemm_profile_enable(int mode) {
+    MEDP_CHECK_ARG(mode >= 0 && mode <= 2, "gemm_profile_enable: mode must be 0 (off), 1 (HIP events) or 2 (in-kernel clock)");
+    if (mode == 1) {
+        g_prof.used = 0;
+        g_prof.flops = 0.0;
+    }
+    if (mode == 2) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!g_prof.slots || g_prof.slot_dev != dev) {
+            hipError_t e = hipMalloc((void**)&g_prof.slots, MAX_PROF_SLOTS * 4 * sizeof(unsigned long long));
+            if (e != hipSuccess) { medp_set_error("gemm_profile_enable: %s", hipGetErrorString(e)); return (int)e; }
+            g_prof.slot_dev = dev;
+        }
+        hipError_t e = hipMemset(g_prof.slots, 0, MAX_PROF_SLOTS * 4 * sizeof(unsigned long long));
+        if (e != hipSuccess) { medp_set_error("gemm_profile_enable: %s", hipGetErrorString(e)); return (int)e; }
+        g_prof.slot_flops.clear();
+    }
+    g_prof.mode = mode;      // mode 0 keeps what was gathered for collect()
     return 0;
 }
 
 extern "C" int medp_gemm_profile_collect(double* total_ms, long long* n_launches, double* total_flops) {
     MEDP_CHECK_ARG(total_ms && n_launches && total_flops, "gemm_profile_collect: null argument");
     double ms = 0.0;
+    if (!g_prof.slot_flops.empty()) {        // in-kernel clocks: the caller has synchronised the device
+        const size_t n = g_prof.slot_flops.size();
+        std::vector<unsigned long long> h(n * 4);
+        hipError_t e = hipMemcpy(h.data(), g_prof.slots, n * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { medp_set_error("gemm_profile_collect: %s", hipGetErrorString(e)); return (int)e; }
+        int khz = 100000;
+        (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, g_prof.slot_dev);
+        double fl = 0.0;
+        long long cnt = 0;
+        for (size_t i = 0; i < n; ++i) {
+            if (h[4 * i + 1] <= h[4 * i]) continue;      // never executed
+            ms += (double)(h[4 * i + 1] - h[4 * i]) / (double)khz;
+            fl += g_prof.slot_flops[i];
+            ++cnt;
+        }
+        *total_ms = ms;
+        *n_launches = cnt;
+        *total_flops = fl;
+        return 0;
+    }
     for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
         hipError_t e = hipEventSynchronize(g_prof.ev[i + 1]);
         if (e != hipSuccess) { medp_set_error("gemm_profile_collect: %s", hipGetErrorString(e)); return (int)e; }
@@ -531,11 +570,9 @@ int medp_gemm_bf16_nt_tagged(int tag, const void* A, const void* W, void* C, int
     hipStream_t s = (hipStream_t)stream;
     static const int force = [] { const char* e = getenv("MEDP_GEMM_VARIANT"); return e ? atoi(e) : 0; }();   // 1 = v1, 2 = v2 (A/B tests)
     const bool use_v2 = force == 2;
-    const bool use_v4 = force == 4;                                  // persistent variant (gemm_bf16_v4.hip)
     const bool use_v3 = force == 3 || (force == 0 && M >= 2048 && N >= 256);
-    const MedpGemmArgs a4{A, W, C, M, N, K, lda, ldw, ldc, bias, scale, residual, ldr, act, out_bf16};
+    MedpGemmArgs a4{A, W, C, M, N, K, lda, ldw, ldc, bias, scale, residual, ldr, act, out_bf16, nullptr};
     if (N <= 64) return launch<128, 64, 0>(p, s);
-    const bool use_v5 = force == 5 && M >= 2048 && N >= 256;         // 256 x 256 tiles, 128 x 128 per wave (gemm_bf16_v5.hip)
     // v6 (256 x 256 x 64, 8 waves ping-pong, gemm_bf16_v6.hip) runs ONE workgroup per CU: default once there are enough
     // 256^2 tiles to occupy most of the chip (the CXR-encoder shapes: 195 / 585 / 780 tiles); v3 keeps the smaller grids
     const int tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
@@ -551,12 +588,14 @@ int medp_gemm_bf16_nt_tagged(int tag, const void* A, const void* W, void* C, int
         return medp_gemm_v6_launch(a4, tg, stream);
     };
     if (use_v6 && tag != 1) return launch_v67(0);
-    if (use_v5 && tag != 1) return medp_gemm_v5_launch(a4, 0, stream);
-    if (use_v4 && tag != 1 && M >= 2048 && N >= 256) return medp_gemm_v4_launch(a4, 0, stream);
     if (use_v3 && tag != 1) return launch_v3<0>(p, s);
     if (use_v2 && tag != 1) return launch_v2<0>(p, s);
     if (tag == 1) {
-        const bool prof = g_prof.on;
+        const bool prof = g_prof.mode == 1;
+        if (g_prof.mode == 2 && use_v6 && g_prof.slot_flops.size() < MAX_PROF_SLOTS) {
+            a4.prof = g_prof.slots + 4 * g_prof.slot_flops.size();
+            g_prof.slot_flops.push_back(2.0 * (double)M * (double)N * (double)K);
+        }
         if (prof) {
             if (g_prof.used + 2 > g_prof.ev.size()) {
                 for (int i = 0; i < 2; ++i) {
@@ -567,8 +606,7 @@ int medp_gemm_bf16_nt_tagged(int tag, const void* A, const void* W, void* C, int
             }
             hipEventRecord(g_prof.ev[g_prof.used], s);
         }
-        const int rc = use_v6 ? launch_v67(1) : use_v5 ? medp_gemm_v5_launch(a4, 1, stream) : use_v4 ? medp_gemm_v4_launch(a4, 1, stream)
-                              : (use_v3 ? launch_v3<1>(p, s) : (use_v2 ? launch_v2<1>(p, s) : launch<128, 128, 1>(p, s)));
+        const int rc = use_v6 ? launch_v67(1) : (use_v3 ? launch_v3<1>(p, s) : (use_v2 ? launch_v2<1>(p, s) : launch<128, 128, 1>(p, s)));
         if (prof) {
             hipEventRecord(g_prof.ev[g_prof.used + 1], s);
             g_prof.used += 2;

@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(const TnParams p) 
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     if (nsteps > 0) stage(0, 0);
+    MEDP_WAIT_LDS_DMA();
     __syncthreads();
     // transposing read: lane 4q+pp of a 16-lane group addresses row q, columns 4pp..4pp+3; group kq covers rows 8kq..8kq+7
     const int tq = il >> 2, tp = il & 3;
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(const TnParams p) 
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[j], fy[i], acc[i][j], 0, 0, 0);
+        MEDP_WAIT_LDS_DMA();   // slab st+1 (issued at the top of this iteration) has landed
         __syncthreads();
     }
     float* C = p.C + (size_t)blockIdx.y * p.slab_stride;

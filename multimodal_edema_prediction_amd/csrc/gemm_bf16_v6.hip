@@ -28,7 +28,7 @@
 #include <stdlib.h>
 
 #include "common.h"
-#include "gemm_v4.h"
+#include "gemm_variants.h"
 
 namespace {
 
@@ -69,6 +69,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v6_kernel(const MedpGemmA
     const bf16_t* A = (const bf16_t*)p.A;
     const bf16_t* W = (const bf16_t*)p.W;
     const bf16_t* zero = (const bf16_t*)g_zero16_v6;
+    MEDP_PROF_ENTER(p.prof);
 
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int bid = blockIdx.x;
@@ -270,16 +271,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v6_kernel(const MedpGemmA
         }
         MEDP_WAVE_LDS_SYNC();
     }
+    MEDP_PROF_LEAVE(p.prof);
 }
 
 template <int TAG>
 int launch_v6(const MedpGemmArgs& a, hipStream_t stream) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    static bool attr_set = false;
-    if (!attr_set) {
+    MEDP_ONCE_PER_DEVICE({
         hipFuncSetAttribute((const void*)gemm_bf16_nt_v6_kernel<TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
-    }
+    });
     gemm_bf16_nt_v6_kernel<TAG><<<tiles, 512, LDS_BYTES, stream>>>(a);
     MEDP_LAUNCH_CHECK("medp_gemm_bf16_nt(v6)");
     return 0;

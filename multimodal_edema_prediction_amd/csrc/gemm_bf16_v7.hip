@@ -22,7 +22,7 @@
 #include <atomic>
 
 #include "common.h"
-#include "gemm_v4.h"
+#include "gemm_variants.h"
 
 namespace {
 
@@ -87,6 +87,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v7_kernel(const MedpGemmA
     const bf16_t* A = (const bf16_t*)p.A;
     const bf16_t* W = (const bf16_t*)p.W;
     const bf16_t* zero = (const bf16_t*)g_zero16_v7;
+    MEDP_PROF_ENTER(p.prof);
 
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int ntiles = tiles_m * tiles_n;
@@ -397,6 +398,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v7_kernel(const MedpGemmA
             for (int i = 0; i < 9; ++i) __hip_atomic_store(slot + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    MEDP_PROF_LEAVE(p.prof);
 }
 
 std::atomic<unsigned> g_ring_next{0}, g_capture_next{0};
@@ -404,13 +406,16 @@ unsigned long long* g_trace = nullptr;   // debug hook, see medp_dbg_gemm_v7_tra
 
 template <int TAG>
 int launch_v7(const MedpGemmArgs& a, hipStream_t stream) {
-    static bool attr_set = false;
-    static unsigned* slots = nullptr;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_bf16_nt_v7_kernel<TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (hipGetSymbolAddress((void**)&slots, HIP_SYMBOL(g_v7_slots)) != hipSuccess || !slots) return -1;
-        attr_set = true;
-    }
+    static unsigned* slots_of[MEDP_MAX_DEVICES] = {};      // the ticket blocks are a __device__ symbol: one copy per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    MEDP_ONCE_PER_DEVICE({
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_v7_kernel<TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        unsigned* sp = nullptr;
+        if (hipGetSymbolAddress((void**)&sp, HIP_SYMBOL(g_v7_slots)) == hipSuccess) slots_of[dev % MEDP_MAX_DEVICES] = sp;
+    });
+    unsigned* slots = slots_of[dev % MEDP_MAX_DEVICES];
+    if (!slots) return -1;
     // a ticket block nobody else is using: captured launches (replayed for the life of the graph) never share one
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     hipStreamIsCapturing(stream, &cs);

@@ -195,15 +195,17 @@ class CXREncoder(nn.Module):
         self._frozen = freeze
 
     def _try_load_pretrained(self, model_name: str) -> None:
-        """`AutoModel.from_pretrained(model_name)` (model file :137) when the weights are reachable (local path / cache);
-        offline they are not, and the encoder keeps its seeded random initialisation (synthetic benchmark)."""
+        """`AutoModel.from_pretrained(model_name)` (model file :137).  Like the reference this RAISES when the weights cannot
+        be had (offline: no local path / cache) — a frozen random ViT would silently feed noise features to the fusion head.
+        Random initialisation is only ever taken for `model_name == "synthetic"` or an explicit `config=` (the benchmark)."""
+        from transformers import AutoModel
         try:
-            from transformers import AutoModel
             hf = AutoModel.from_pretrained(model_name, local_files_only=True)
-        except Exception as e:          # no network / no cache here
-            print(f"[CXREncoder] pretrained weights for {model_name!r} unavailable ({type(e).__name__}); using random init")
-            return
-        self.backbone.load_state_dict(hf.state_dict(), strict=True)
+        except Exception as e:
+            raise RuntimeError(f"CXREncoder: pretrained weights for {model_name!r} are not available locally "
+                               f"({type(e).__name__}: {e}); pass a local checkpoint directory, or model_name='synthetic' "
+                               "for seeded random weights (synthetic benchmark only)") from e
+        self.backbone.load_state_dict(hf.state_dict(), strict=True)      # key / shape mismatches fail loudly too
 
     def train(self, mode: bool = True):
         super().train(mode)

@@ -174,6 +174,109 @@ class GradAllReducer:
             self._opt_hook.remove()
 
 
+class FlatGradArena:
+    """Flat fp32 gradient arena for the captured-graph step (graph_step.py): every parameter that takes part in the step gets
+    its `.grad` as a VIEW into one flat buffer, so backward accumulates straight into the message RCCL sends (no packing
+    kernels) and the whole exchange is `n_buckets` large collectives (xGMI is point-to-point and latency-bound at these
+    sizes: few, large messages).
+
+    `used`: the parameters that really receive a gradient in a step (found by the caller from one warm-up backward; the
+    set is a property of the model, hence the same on every rank).  Parameters outside it keep `.grad = None`, exactly like
+    DDP with `find_unused_parameters=True` (trainer.py:217) leaves them: the optimiser skips them, so neither weight decay
+    nor Adam state ever touches DuETT's SSL heads (duett.py:110-122) whatever the world size.
+
+    Buckets are contiguous slices in REVERSE parameter order position (gradients become ready roughly in reverse registration
+    order), so `all_reduce(bucket=i, async_op=True)` can be issued as soon as a backward segment has produced bucket i.
+    """
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], used: Optional[Iterable[torch.nn.Parameter]] = None, group=None,
+                 n_buckets: int = 1):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.all_params = [p for p in params if p.requires_grad]
+        if not self.all_params:
+            raise ValueError("FlatGradArena: no trainable parameters")
+        used_ids = None if used is None else {id(p) for p in used}
+        self.params = [p for p in self.all_params if used_ids is None or id(p) in used_ids]
+        self.unused = [p for p in self.all_params if used_ids is not None and id(p) not in used_ids]
+        if not self.params:
+            raise ValueError("FlatGradArena: no parameter receives a gradient")
+        dev, dtype = self.params[0].device, self.params[0].dtype
+        if any(p.device != dev or p.dtype != dtype for p in self.params):
+            raise ValueError("FlatGradArena: parameters must share one device and dtype")
+        order = list(reversed(self.params))                      # backward order
+        total = sum(p.numel() for p in order)
+        self.flat = torch.zeros(total, dtype=dtype, device=dev)
+        self.slots, off = {}, 0
+        for p in order:
+            self.slots[id(p)] = (off, p.numel())
+            off += p.numel()
+        n_buckets = max(1, min(int(n_buckets), len(order)))
+        per = (total + n_buckets - 1) // n_buckets
+        self.bucket_bounds, start, acc = [], 0, 0
+        for p in order:
+            acc += p.numel()
+            if acc - start >= per and len(self.bucket_bounds) < n_buckets - 1:
+                self.bucket_bounds.append((start, acc))
+                start = acc
+        self.bucket_bounds.append((start, total))
+        self.bytes_per_step = total * self.flat.element_size()
+        self._avg = None
+
+    def bind(self, zero: bool = True) -> None:
+        """Point every used parameter's `.grad` at its arena slice (unused ones: None)."""
+        if zero:
+            self.flat.zero_()
+        for p in self.params:
+            off, n = self.slots[id(p)]
+            p.grad = self.flat[off:off + n].view_as(p)
+        for p in self.unused:
+            p.grad = None
+
+    def bucket_of(self, p: torch.nn.Parameter) -> int:
+        off, _ = self.slots[id(p)]
+        for i, (a, b) in enumerate(self.bucket_bounds):
+            if a <= off < b:
+                return i
+        raise KeyError("parameter is not in the arena")
+
+    def all_reduce(self, bucket: Optional[int] = None, async_op: bool = False, force: bool = False):
+        """Mean over ranks of the whole arena (bucket=None) or of one bucket.  Returns the work handle when async.
+        `force`: issue the collective even on a size-1 group (one-GPU rehearsal of the N > 1 step)."""
+        if not dist.is_initialized() or (self.world == 1 and not force):
+            return None
+        if self._avg is None:
+            self._avg = dist.get_backend(self.group) == "nccl"
+        a, b = (0, self.flat.numel()) if bucket is None else self.bucket_bounds[bucket]
+        view = self.flat[a:b]
+        if self._avg:
+            return dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+        work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)   # gloo has no AVG
+        if async_op:
+            return _ScaledWork(work, view, self.world)
+        view.div_(self.world)
+        return None
+
+
+class _ScaledWork:
+    def __init__(self, work, view, world):
+        self.work, self.view, self.world = work, view, world
+
+    def wait(self):
+        self.work.wait()
+        self.view.div_(self.world)
+
+
+def find_used_parameters(params: Iterable[torch.nn.Parameter], run_backward) -> list:
+    """One backward with every `.grad` cleared tells which parameters the step really reaches (the static answer to DDP's
+    `find_unused_parameters`).  `run_backward()` must run forward + backward once."""
+    ps = [p for p in params if p.requires_grad]
+    for p in ps:
+        p.grad = None
+    run_backward()
+    return [p for p in ps if p.grad is not None]
+
+
 @torch.no_grad()
 def gather_for_eval(*tensors: torch.Tensor, group=None):
     """All-gather evaluation outputs so AUROC is computed on the full split (the reference evaluates rank 0's shard only,

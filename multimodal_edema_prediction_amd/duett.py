@@ -16,7 +16,6 @@ import ctypes
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import abi
 from . import functional as Fn
@@ -188,42 +187,102 @@ class Model(nn.Module):
         return nn.Sequential(nn.Linear(1, d_hidden), nn.Tanh(), nn.Linear(d_hidden, d_embedding))
 
     # ------------------------------------------------------------------------------------------ a3: batch assembly
+    _FEATS_SID = 200          # RNG stream ids 200..202 of the augmentation draws (values, dropped timesteps, static)
+
+    @staticmethod
+    def _as_rows_of_one_buffer(ts):
+        """(base_ptr, stride_in_elements) when the per-sample tensors are equally shaped, contiguous, equally spaced views of
+        one buffer (the collate of a resident batch / the static buffers of a captured step), else None."""
+        t0 = ts[0]
+        if not all(t.shape == t0.shape and t.is_contiguous() and t.dtype == torch.float32 for t in ts):
+            return None
+        if len(ts) == 1:
+            return t0.data_ptr(), t0.numel()
+        step = ts[1].data_ptr() - t0.data_ptr()
+        if step < t0.numel() * 4 or step % 4 or any(t.data_ptr() != t0.data_ptr() + i * step for i, t in enumerate(ts)):
+            return None
+        return t0.data_ptr(), step // 4
+
+    def _device_table(self, values, dtype):
+        """Small host list -> device tensor, cached on its content (a captured step sees the same views every time)."""
+        key = (dtype, tuple(values))
+        cache = self.__dict__.setdefault("_tables", {})
+        if key not in cache:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("feats_to_input: a new pointer/length table would have to be uploaded inside a graph capture; "
+                                   "pass views of one stacked buffer (graph_step.py does) or warm the step up first")
+            if len(cache) >= 16:
+                cache.pop(next(iter(cache)))
+            cache[key] = torch.tensor(list(values), dtype=dtype, device=self.device)
+        return cache[key]
+
     def feats_to_input(self, x, batch_size, limits=None):
-        """Same contract as duett.py:159-187: (tuples of per-sample tensors) -> (xs_static [B,Ds], xs_ts [B,T,2V+1],
-        xs_times [B,T], n_timesteps).  Uniform-length, un-augmented batches (the training configuration) take a
-        stack-only fast path; ragged / augmented batches follow the reference step by step (same RNG draws)."""
+        """Same contract as duett.py:159-187: (tuples of per-sample tensors) -> (xs_static [B,Ds], xs_ts [B,Tpad,2V+1],
+        xs_times [B,Tpad], n_timesteps) — ONE launch of `medp_feats_to_input` instead of the host loop over the batch:
+        truncation to the last max_len steps, the mask column, zero padding to the longest series and the training
+        augmentation all happen on the device.  Inputs may live on the host (one concatenated upload) or on
+        the device (rows of one stacked buffer: no copy at all; separate tensors: a pointer table).  With augmentation off the
+        result is bit-identical to the reference's; with it on the draws come from the library's counter RNG, not torch's.
+        Unlike the reference the caller's tensors are never modified in place."""
+        abi.require_gpu()
         xs_ts, xs_static, times = x
-        xs_ts, times = list(xs_ts), list(times)
+        xs_ts, xs_static, times = list(xs_ts), list(xs_static), list(times)
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("feats_to_input: the model is on %s; the batch assembly kernel needs the GPU (no CPU fallback)" % dev)
+        B = len(xs_ts)
+        V2 = int(xs_ts[0].shape[1])
+        V, Ds = V2 // 2, int(xs_static[0].shape[0])
+        lens = [int(f.shape[0]) for f in xs_ts]
+        if any(int(t.shape[0]) != n for t, n in zip(times, lens)) or any(int(f.shape[1]) != V2 for f in xs_ts):
+            raise ValueError("feats_to_input: every series needs [T_i, 2V] features and [T_i] times")
+        n_timesteps = [min(n, self.max_len) for n in lens]
+        Tpad = max(n_timesteps)
         aug = self.training and not self.pretrain
-        T0 = xs_ts[0].shape[0]
-        uniform = all(f.shape[0] == T0 for f in xs_ts) and T0 <= self.max_len
-        if uniform and not (aug and (self.aug_noise > 0 or self.aug_mask > 0)):
-            dev = self.device
-            ts = torch.stack(xs_ts).to(dev)
-            out = torch.zeros((ts.shape[0], T0, ts.shape[2] + 1), dtype=ts.dtype, device=dev)
-            out[:, :, :-1] = ts
-            return (torch.stack(list(xs_static)).to(dev), out, torch.stack(times).to(dev), [len(t) for t in times])
-        for i, f in enumerate(xs_ts):
-            n_vars = f.shape[1] // 2
-            if f.shape[0] > self.max_len:
-                f = f[-self.max_len:]
-                times[i] = times[i][-self.max_len:]
-            if aug and self.aug_noise > 0:
-                f[:, :n_vars] += self.aug_noise * torch.randn_like(f[:, :n_vars]) * f[:, n_vars:]
-            f = torch.cat((f, torch.zeros_like(f[:, :1])), dim=1)
-            if aug and self.aug_mask > 0:
-                mask = torch.rand(f.shape[0]) < self.aug_mask
-                f[mask, :] = 0.
-                f[mask, -1] = 1.
-            xs_ts[i] = f
-        n_timesteps = [len(ts) for ts in times]
-        pad_to = int(np.max(n_timesteps))
-        xs_ts = torch.stack([F.pad(t, (0, 0, 0, pad_to - t.shape[0])) for t in xs_ts]).to(self.device)
-        xs_times = torch.stack([F.pad(t, (0, pad_to - t.shape[0])) for t in times]).to(self.device)
-        xs_static = torch.stack(list(xs_static)).to(self.device)
-        if aug and self.aug_noise > 0:
-            xs_static += self.aug_noise * torch.randn_like(xs_static)
-        return xs_static, xs_ts, xs_times, n_timesteps
+        noise, maskp = (float(self.aug_noise), float(self.aug_mask)) if aug else (0.0, 0.0)
+        keep = []                                   # temporaries the launch reads
+
+        def locate(ts, width):
+            """-> (ptr_table, base, stride) for a list of [T_i(, width)] series"""
+            if all(t.device.type == "cpu" for t in ts):                       # host batch: one upload
+                flat = torch.cat([t.reshape(-1) for t in ts]).to(dev, torch.float32, non_blocking=True)
+                keep.append(flat)
+                if len(set(lens)) == 1:
+                    return None, flat.data_ptr(), lens[0] * width
+                offs, o = [], 0
+                for n in lens:
+                    offs.append(flat.data_ptr() + 4 * o)
+                    o += n * width
+                return self._device_table(offs, torch.int64), None, 0
+            ts = [t if (t.device == dev and t.dtype == torch.float32 and t.is_contiguous()) else t.to(dev, torch.float32).contiguous() for t in ts]
+            keep.extend(ts)
+            rows = self._as_rows_of_one_buffer(ts)
+            if rows is not None:
+                return None, rows[0], rows[1]
+            return self._device_table([t.data_ptr() for t in ts], torch.int64), None, 0
+
+        ts_tab, ts_base, ts_stride = locate(xs_ts, V2)
+        tm_tab, tm_base, tm_stride = locate(times, 1)
+        srows = self._as_rows_of_one_buffer(xs_static) if all(t.device == dev for t in xs_static) else None
+        if srows is not None and (B == 1 or srows[1] == Ds):
+            static_ptr = srows[0]
+        else:
+            st = torch.stack([t.to(torch.float32) for t in xs_static]).to(dev).contiguous()
+            keep.append(st)
+            static_ptr = st.data_ptr()
+        uniform = len(set(lens)) == 1
+        len_tab = None if uniform else self._device_table(lens, torch.int32)
+        out_ts = torch.empty((B, Tpad, V2 + 1), dtype=torch.float32, device=dev)
+        out_tm = torch.empty((B, Tpad), dtype=torch.float32, device=dev)
+        out_st = torch.empty((B, Ds), dtype=torch.float32, device=dev)
+        seed = 0
+        if noise > 0 or maskp > 0:
+            from . import autograd_ops as A
+            seed = A.next_seed()
+        check(lib().medp_feats_to_input(ptr(ts_tab), ts_base, ts_stride, ptr(tm_tab), tm_base, tm_stride, ptr(len_tab),
+                                        lens[0] if uniform else 0, static_ptr, ptr(out_ts), ptr(out_tm), ptr(out_st), B, V, Ds,
+                                        int(self.max_len), Tpad, noise, maskp, seed, self._FEATS_SID, stream()), "feats_to_input")
+        return out_st, out_ts, out_tm, n_timesteps
 
     # ------------------------------------------------------------------------------------------ weight preparation
     def _prepare(self):

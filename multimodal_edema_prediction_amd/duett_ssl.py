@@ -14,33 +14,34 @@ F32 = torch.float32
 
 
 def pretrain_prep_batch(model, x, batch_size):
-    """duett.py:189-237 — same numpy Generator draws, in the same order, as the reference."""
+    """duett.py:189-237.  The random choices are the reference's — the same numpy Generator calls in the same order (masked
+    timestep and masked event per sample, then the [B, V] variable-dropout table) — drawn on the host; everything they drive
+    (target gathers, index_put of the masked row / event columns, the keep multiply) is ONE launch of `medp_ssl_mask_batch`."""
     if model.pretrain_masked_steps != 1:
         raise NotImplementedError("pretrain_masked_steps > 1 is not built (the reference default is 1)")
     xs_static, xs_ts, xs_times, n_timesteps = model.feats_to_input(x, batch_size)
-    n_vars = (xs_ts.shape[2] - 1) // 2
-    y_ts, y_nobs, y_events, y_events_mask = [], [], [], []
-    clipped = xs_ts.clone()
-    for b, n in enumerate(n_timesteps):
-        mask_i = n if n < 2 else model.rng.choice(np.arange(0, n))
-        y_ts.append(xs_ts[b, mask_i, :n_vars])
-        y_nobs.append(xs_ts[b, mask_i, n_vars:2 * n_vars])
-        clipped[b, mask_i, :] = 0.0
-        clipped[b, mask_i, -1] = 1.0
+    B, T, Fd = xs_ts.shape
+    n_vars = (Fd - 1) // 2
+    mask_t, events = [], []
+    for n in n_timesteps:
+        mask_t.append(int(n if n < 2 else model.rng.choice(np.arange(0, n))))
         if model.predict_events:
-            ev = model.rng.choice(np.arange(0, model.d_time_series_num))
-            y_events.append(xs_ts[b, :, ev])
-            y_events_mask.append(xs_ts[b, :, ev + n_vars].clip(0, 1))
-            clipped[b, :, ev] = 0
-            clipped[b, :, ev + n_vars] = -1
-    y_ts, y_masks = torch.stack(y_ts), torch.stack(y_nobs).clip(0, 1)
-    if y_events:
-        y_events, y_events_mask = torch.stack(y_events), torch.stack(y_events_mask)
-    if model.pretrain_dropout > 0:
-        keep = torch.tensor(model.rng.random((batch_size, n_vars)) > model.pretrain_dropout, device=xs_ts.device)
-        keep = torch.logical_or(1 - y_masks, keep)
-        keep = torch.cat((keep.tile(1, 2), torch.ones((batch_size, 1), device=keep.device)), dim=1)
-        clipped = clipped * torch.logical_or(keep.unsqueeze(1), clipped == -1)
+            events.append(int(model.rng.choice(np.arange(0, model.d_time_series_num))))
+    if max(mask_t) >= T:
+        raise IndexError(f"index {max(mask_t)} is out of bounds for dimension 1 with size {T}")     # what the reference's indexing raises
+    keep = model.rng.random((batch_size, n_vars)) > model.pretrain_dropout if model.pretrain_dropout > 0 else None
+    dev = xs_ts.device
+    mt = torch.tensor(mask_t, dtype=torch.int32, device=dev)
+    ev = torch.tensor(events, dtype=torch.int32, device=dev) if events else None
+    kp = torch.from_numpy(np.ascontiguousarray(keep).astype(np.uint8)).to(dev) if keep is not None else None
+    clipped = torch.empty_like(xs_ts)
+    y_ts = torch.empty((B, n_vars), dtype=F32, device=dev)
+    y_masks = torch.empty((B, n_vars), dtype=F32, device=dev)
+    y_events = torch.empty((B, T), dtype=F32, device=dev) if events else []
+    y_events_mask = torch.empty((B, T), dtype=F32, device=dev) if events else []
+    check(lib().medp_ssl_mask_batch(ptr(xs_ts), ptr(mt), ptr(ev), ptr(kp), ptr(clipped), ptr(y_ts), ptr(y_masks),
+                                    ptr(y_events) if events else None, ptr(y_events_mask) if events else None, B, T, n_vars, stream()),
+          "ssl_mask_batch")
     return (xs_static, clipped, xs_times, n_timesteps), y_ts, y_masks, y_events, y_events_mask
 
 

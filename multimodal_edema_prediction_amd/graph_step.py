@@ -1,167 +1,198 @@
-"""Whole-step HIP graph: the MI355X-first way to run the training step (SURVEY.md §7 "HIP streams and graphs instead of a
+"""Whole-step HIP graphs: the MI355X-first way to run the training step (SURVEY.md §7 "HIP streams and graphs instead of a
 tracing compiler").  The eager step of engine.py issues ~700 launches from Python and is host-bound; here the complete
-`train_teacher_dual_pathology_batch` arithmetic — both frozen encoders, the fusion head forward, DualPathologyLoss, the
-backward of every trainable parameter and the fused AdamW update — is captured ONCE into a hipGraph and replayed per
-step.  Everything that must differ between replays lives in device memory: the input batch (static buffers), the dropout
-RNG epoch (`medp_rng_set_epoch_ptr`), the optimiser step count (`FusedAdamW.dev_step`, advanced by the captured optimiser itself) and the per-group learning rates
-(the descriptor table is re-uploaded from pinned host memory by a captured memcpy node).
+step arithmetic — frozen encoders, trainable forward, loss, backward of every trainable parameter, fused AdamW — is captured
+ONCE into hipGraphs and replayed per step.  Everything that must differ between replays lives in device memory: the input
+batch (static buffers), the dropout RNG epoch (`medp_rng_set_epoch_ptr`), the optimiser step count (`FusedAdamW.dev_step`,
+advanced by the captured optimiser itself) and the optimiser's descriptor table with this step's learning rates (uploaded,
+stream-ordered, right before each replay through a ring of pinned staging buffers: optim.FusedAdamW.refresh_lrs).
 
-N > 1: forward+backward are one graph accumulating into a flat fp32 gradient arena, the arena is all-reduced by RCCL
-between the two replays (one collective, 14.8 MB), and the optimiser is a second graph.  With `pipeline_cxr` the frozen
-encoder of the next batch CAN be split across the two graphs (`MEDP_SPLIT_VIT_LAYERS=L`, `medp_vit_forward_part`: layers
-[0, L) beside forward/backward, layers [L, 12) beside the optimiser) so that the collective and the update need not wait for
-the whole encoder.  Measured on one GPU in the N > 1 arrangement it LOSES (L = 8 / 7 / 5: 10.2 / 9.9 / 9.5 k samples/s
-against 11.5 k with the encoder whole in the first graph, bit-identical results): the two branches of the step time-share
-the CUs rather than fill each other's gaps, so layers moved behind the optimiser simply run later.  Default 0 (whole).
+Two step classes share the machinery:
+  * `GraphedTeacherStep`  — `engine.train_teacher_dual_pathology_batch` (BASELINE configs[2], engine.py:135-190)
+  * `GraphedStudentStep`  — `engine.train_student_batch` (BASELINE configs[3], engine.py:270-301): frozen teacher forward under
+    no-grad + student (DuETT trained end to end) forward/backward + StudentKDLoss.
 
-`pipeline_cxr=True` (software pipelining across steps): the CXR encoder is frozen, so its tokens for batch k+1 depend on
-nothing the training step of batch k produces.  The captured step then holds THREE parallel branches: the image half +
-backward + optimiser of batch k (reading the tokens the previous replay left in `tok_cur`), the time-series half on the
-side stream, and the encoder forward of batch k+1 on a third stream; the replay ends by moving the new tokens into
-`tok_cur`.  Every replay still runs exactly one encoder forward, one fusion forward/backward and one update — the
-encoder pass is just shifted one batch ahead (the first batch's pass happens in `prime`).  Results are bit-identical to the
-unpipelined step (tests/test_gpu_pipeline.py).
+Software pipelining of the FROZEN part: whatever is frozen (the teacher's CXR encoder; in the student step the whole teacher)
+depends on nothing the update of batch k produces, so its forward for batch k+1 runs beside the training step of batch k and
+hands its result over at the end of the replay.  Every replay still runs exactly one frozen forward, one trainable
+forward/backward and one update; results are bit-identical to the unpipelined step (tests/test_gpu_pipeline.py).
+
+One GPU: ONE graph holds all of it (three parallel branches).  N > 1 (`split`): gradients accumulate into a flat fp32
+arena (dp.FlatGradArena: only parameters that really receive a gradient, the others keep `.grad = None` as under DDP's
+find_unused_parameters) and the step is three graphs on two streams:
+      main stream :  [forward/backward graph] -> RCCL mean all-reduce of the arena -> [optimiser graph]
+      frozen stream: [frozen-forward graph of batch k+1] .............................................. join
+so the collective (14.8 MB teacher / 35.6 MB student) and the update run UNDER the frozen encoder's GEMMs of the next batch —
+the long pole of the step — instead of between two serial graphs.  No collective is captured into a graph.
 """
 from __future__ import annotations
 
-import os
-
 import torch
-import torch.distributed as dist
 
-from . import engine
+from . import dp, engine
 from .abi import check, lib, ptr, stream
 
 
-class GraphedTeacherStep:
+def _stacked(v):
+    """The collate layout is tuples of per-sample tensors; an already stacked tensor is taken as is."""
+    return v if torch.is_tensor(v) else torch.stack(tuple(v))
+
+
+class _GraphedStep:
+    """Capture / replay machinery common to both steps.  Subclasses provide `_frozen_forward()` (frozen part for the NEXT
+    batch, on the current stream, returns nothing), `_train_fwd_bwd()` (returns the output dict) and `_hand_over()`."""
+
+    def _setup(self, optimizer, device, world, group, split, pipeline, warmup, before_capture):
+        self.opt, self.device, self.world, self.group = optimizer, device, world, group
+        self.pipeline = bool(pipeline)
+        self.epoch = torch.zeros(1, dtype=torch.int32, device=device)
+        check(lib().medp_rng_set_epoch_ptr(ptr(self.epoch)), "rng_set_epoch_ptr")
+        self.params = [p for g in optimizer.param_groups for p in g["params"] if p.requires_grad]
+        self.split = bool(split) or world > 1
+        self.arena = None
+        self.force_collective = False      # bench.py MEDP_FORCE_PG=1: really call RCCL on a size-1 group (one-GPU rehearsal of N > 1)
+        self._captured = False
+        self.frozen_stream = torch.cuda.Stream(device=device) if self.pipeline else None
+        # warm-up on a side stream (allocator pools, lazy workspaces, optimiser state), as torch.cuda.graphs requires
+        s = torch.cuda.Stream(device=device)
+        s.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(s):
+            for it in range(max(int(warmup), 1)):
+                if self.split and self.arena is None:
+                    # the first backward tells which parameters the step reaches; only those enter the arena
+                    # (not a training step: module buffers — BatchNorm running statistics — and the dropout epoch are restored)
+                    bufs = [(b, b.detach().clone()) for m in self._stateful_modules() for b in m.buffers()]
+                    used = dp.find_used_parameters(self.params, lambda: (self._advance(), self._whole_fwd_bwd()))
+                    self.arena = dp.FlatGradArena(self.params, used=used, group=group)
+                    self.arena.bind(zero=True)
+                    self.epoch.sub_(1)
+                    for b, saved in bufs:
+                        b.copy_(saved)
+                self._zero_grads()
+                self._advance()
+                self._whole_fwd_bwd()
+                self._allreduce()
+                self.opt.step()
+        torch.cuda.current_stream(device).wait_stream(s)
+        torch.cuda.synchronize(device)
+        self._zero_grads()
+        if before_capture is not None:
+            before_capture()
+        self.g_frozen = self.g_opt = None
+        self.g_fb = torch.cuda.CUDAGraph()
+        if not self.split:
+            with torch.cuda.graph(self.g_fb):
+                self._advance()
+                self.out = self._whole_fwd_bwd()
+                self.opt.step()
+        else:
+            if self.pipeline:
+                self.g_frozen = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_frozen):
+                    self._frozen_forward()
+            with torch.cuda.graph(self.g_fb):
+                self.arena.flat.zero_()
+                self._advance()
+                self.out = self._train_fwd_bwd()
+            self.g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_opt):
+                self.opt.step()
+        torch.cuda.synchronize(device)
+        self._captured = True
+        self.opt._step = int(self.opt.dev_step.item())      # capture ran opt.step() on the host without executing it
+
+    # ---- pieces -------------------------------------------------------------------------------------------------------------
+    def _zero_grads(self):
+        if self.arena is None:
+            self.opt.zero_grad(set_to_none=True)
+        else:
+            self.arena.bind(zero=True)
+
+    def _advance(self):
+        check(lib().medp_counter_advance(ptr(self.epoch), stream()), "counter_advance")
+
+    def _allreduce(self):
+        if self.arena is not None and (self.world > 1 or self.force_collective):
+            self.arena.all_reduce(force=self.force_collective)
+
+    def _whole_fwd_bwd(self):
+        """One-stream-of-control form: the frozen forward of the next batch as a parallel branch inside the same capture."""
+        if not self.pipeline:
+            return self._train_fwd_bwd()
+        cur = torch.cuda.current_stream(self.device)
+        self.frozen_stream.wait_stream(cur)
+        with torch.cuda.stream(self.frozen_stream):
+            self._frozen_forward()
+        out = self._train_fwd_bwd()
+        cur.wait_stream(self.frozen_stream)
+        self._hand_over()
+        return out
+
+    def _replay(self):
+        """refresh_lrs + the graphs of one step, on the current stream (+ the frozen stream when split and pipelined)."""
+        cur = torch.cuda.current_stream(self.device)
+        self.opt.refresh_lrs()                       # this step's learning rates -> device table, ahead of the replay
+        if self.g_opt is None:
+            self.g_fb.replay()
+        else:
+            if self.g_frozen is not None:
+                self.frozen_stream.wait_stream(cur)  # the next batch's inputs were loaded on the main stream
+                with torch.cuda.stream(self.frozen_stream):
+                    self.g_frozen.replay()
+            self.g_fb.replay()
+            self._allreduce()                        # RCCL on its own stream, ordered after g_fb; runs under g_frozen
+            self.g_opt.replay()
+            if self.g_frozen is not None:
+                cur.wait_stream(self.frozen_stream)
+                self._hand_over()
+        self.opt.note_external_step()
+        return self.out
+
+
+class GraphedTeacherStep(_GraphedStep):
     def __init__(self, teacher, loss_fn, optimizer, example_batch: dict, device, world: int = 1, group=None, warmup: int = 3,
                  split: bool = False, before_capture=None, pipeline_cxr: bool = False):
-        self.teacher, self.loss_fn, self.opt, self.device, self.world, self.group = teacher, loss_fn, optimizer, device, world, group
+        self.teacher, self.loss_fn = teacher, loss_fn
         b = engine._move_lists(example_batch, device)
         # static input buffers; the per-sample tuples the model interface wants are views into the stacked buffers
         self.x_ts = torch.stack(b["x_ts"]).contiguous()
         self.x_static = torch.stack(b["x_static"]).contiguous()
         self.bin_ends = torch.stack(b["bin_ends"]).contiguous()
         self.pixels = b["pixel_values"].clone()
-        self.pipeline = bool(pipeline_cxr)
-        if self.pipeline:
+        if pipeline_cxr:
             if any(p.requires_grad for p in teacher.cxr.parameters()):
                 raise ValueError("pipeline_cxr needs a frozen CXR encoder")
             self.pixels_next = self.pixels.clone()
-            self.vit_stream = torch.cuda.Stream(device=device)
             with torch.no_grad():
                 self.tok_cur = teacher.cxr.forward_bf16(self.pixels).clone()
+            self.tok_next = None
             self._expect = None        # id() of the batch whose tokens sit in tok_cur
         self.y_multi = b["y_multi"].clone().float()
         self.y_mask = b["y_multi_mask"].clone().float()
-        self.epoch = torch.zeros(1, dtype=torch.int32, device=device)
-        check(lib().medp_rng_set_epoch_ptr(ptr(self.epoch)), "rng_set_epoch_ptr")
-        self.params = [p for g in optimizer.param_groups for p in g["params"] if p.requires_grad]
-        self.flat_grad = None
-        self.split = split or world > 1
-        if self.split:
-            n = sum(p.numel() for p in self.params)
-            self.flat_grad = torch.zeros(n, dtype=torch.float32, device=device)
-        # split + pipelined: encoder layers [0, vit_split) run in the forward/backward graph, the rest beside the optimiser
-        self.vit_split = 0
-        if self.split and self.pipeline:
-            n_layers = teacher.cxr.backbone.cfg.num_hidden_layers
-            self.vit_split = max(0, min(n_layers, int(os.environ.get("MEDP_SPLIT_VIT_LAYERS", "0"))))
-            if self.vit_split == n_layers:
-                self.vit_split = 0
         engine._set_train_with_frozen_eval(teacher)
-        # warm-up on a side stream (allocator pools, lazy workspaces, optimiser state), as torch.cuda.graphs requires
-        s = torch.cuda.Stream(device=device)
-        s.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.stream(s):
-            for _ in range(warmup):
-                self._zero_grads()
-                self._advance()
-                self._fwd_bwd()
-                self._allreduce()
-                self._opt_step()
-        torch.cuda.current_stream(device).wait_stream(s)
-        torch.cuda.synchronize(device)
-        self._zero_grads()
-        if before_capture is not None:
-            before_capture()                         # e.g. arm the GEMM timing events so they become nodes of the graph
-        self.g_fb = torch.cuda.CUDAGraph()
-        if not self.split:
-            with torch.cuda.graph(self.g_fb):
-                self._advance()
-                self.out = self._fwd_bwd()
-                self.opt.step()
-            self.g_opt = None
-        else:
-            with torch.cuda.graph(self.g_fb):
-                self.flat_grad.zero_()
-                self._advance()
-                self.out = self._fwd_bwd()
-            self.g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_opt):
-                self._opt_step()
-        torch.cuda.synchronize(device)
-        self.opt._step = int(self.opt.dev_step.item())      # capture ran opt.step() on the host without executing it
+        self._setup(optimizer, device, world, group, split, pipeline_cxr, warmup, before_capture)
 
-    # ---- pieces ---------------------------------------------------------------------------------------------------------
-    def _zero_grads(self):
-        if self.flat_grad is None:
-            self.opt.zero_grad(set_to_none=True)
-        else:
-            off = 0
-            self.flat_grad.zero_()
-            for p in self.params:                  # gradients accumulate straight into the flat arena (no packing step)
-                p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
-                off += p.numel()
+    # ---- the three pieces of a step ----------------------------------------------------------------------------------------
+    def _frozen_forward(self):
+        with torch.no_grad():
+            self.tok_next = self.teacher.cxr.forward_bf16(self.pixels_next)      # batch k+1, beside batch k's step
 
-    def _advance(self):
-        check(lib().medp_counter_advance(ptr(self.epoch), stream()), "counter_advance")
+    def _stateful_modules(self):
+        return [self.teacher]
 
-    def _fwd_bwd(self):
+    def _hand_over(self):
+        if not self._captured:             # graph-pool tensors live as long as their graph: nothing to tell the allocator later
+            self.tok_next.record_stream(torch.cuda.current_stream(self.device))
+        self.tok_cur.copy_(self.tok_next)      # after the backward: the weight-gradient GEMM of img_proj reads tok_cur
+
+    def _train_fwd_bwd(self):
         B = self.x_ts.shape[0]
-        tok_next = None
-        if self.pipeline:
-            cur = torch.cuda.current_stream(self.device)
-            self.vit_stream.wait_stream(cur)
-            with torch.cuda.stream(self.vit_stream), torch.no_grad():
-                if self.vit_split:
-                    self.teacher.cxr.forward_bf16_part(self.pixels_next, 0, self.vit_split)      # the rest: _opt_step
-                else:
-                    tok_next = self.teacher.cxr.forward_bf16(self.pixels_next)      # batch k+1, beside batch k's step
         out = self.teacher(tuple(self.x_ts[i] for i in range(B)), tuple(self.x_static[i] for i in range(B)),
                            tuple(self.bin_ends[i] for i in range(B)), self.pixels,
                            **({"_cxr_tokens16": self.tok_cur} if self.pipeline else {}))
         losses = self.loss_fn(out["img_logits"], out["ts_logits"], out["fusion_logits"], self.y_multi, self.y_mask)
         losses["total"].backward()
-        if self.pipeline:
-            cur.wait_stream(self.vit_stream)
-            if not self.vit_split:
-                tok_next.record_stream(cur)
-                self.tok_cur.copy_(tok_next)      # after the backward: the weight-gradient GEMM of img_proj reads tok_cur
         return {"loss": losses["total"].detach(), "img_total": losses["img_total"], "ts_total": losses["ts_total"],
                 "fus_total": losses["fus_total"], "fusion_logits": out["fusion_logits"].detach(), "main_logit": out["main_logit"].detach()}
-
-    def _opt_step(self):
-        """The optimiser; in the split + pipelined step also the remaining encoder layers of the next batch, beside it."""
-        if not self.vit_split:
-            self.opt.step()
-            return
-        cur = torch.cuda.current_stream(self.device)
-        self.vit_stream.wait_stream(cur)
-        with torch.cuda.stream(self.vit_stream), torch.no_grad():
-            n_layers = self.teacher.cxr.backbone.cfg.num_hidden_layers
-            tok_next = self.teacher.cxr.forward_bf16_part(self.pixels_next, self.vit_split, n_layers)
-        self.opt.step()
-        cur.wait_stream(self.vit_stream)
-        tok_next.record_stream(cur)
-        self.tok_cur.copy_(tok_next)
-
-    def _allreduce(self):
-        if self.world > 1 and dist.is_initialized():
-            op = dist.ReduceOp.AVG if dist.get_backend(self.group) == "nccl" else dist.ReduceOp.SUM
-            dist.all_reduce(self.flat_grad, op=op, group=self.group)
-            if op == dist.ReduceOp.SUM:
-                self.flat_grad.div_(self.world)
 
     # ---- one training step --------------------------------------------------------------------------------------------------
     def prime(self, batch: dict) -> None:
@@ -172,11 +203,9 @@ class GraphedTeacherStep:
 
     def load_batch(self, batch: dict) -> None:
         """Copy a batch (host or device) into the static input buffers (async on the current stream)."""
-        def stacked(v):           # the collate layout is tuples of per-sample tensors; an already stacked tensor is taken as is
-            return v if torch.is_tensor(v) else torch.stack(tuple(v))
-        self.x_ts.copy_(stacked(batch["x_ts"]), non_blocking=True)
-        self.x_static.copy_(stacked(batch["x_static"]), non_blocking=True)
-        self.bin_ends.copy_(stacked(batch["bin_ends"]), non_blocking=True)
+        self.x_ts.copy_(_stacked(batch["x_ts"]), non_blocking=True)
+        self.x_static.copy_(_stacked(batch["x_static"]), non_blocking=True)
+        self.bin_ends.copy_(_stacked(batch["bin_ends"]), non_blocking=True)
         if not self.pipeline:                        # pipelined: this batch's pixels were consumed by the previous replay
             self.pixels.copy_(batch["pixel_values"], non_blocking=True)
         self.y_multi.copy_(batch["y_multi"], non_blocking=True)
@@ -194,12 +223,10 @@ class GraphedTeacherStep:
                            ("y_multi_mask", "y_mask"), ("pixel_values", "pixels_next"))}
             self.h2d_done, self.stage_free = torch.cuda.Event(), torch.cuda.Event()
             self.stage_free.record(torch.cuda.current_stream(self.device))
-        def stacked(v):
-            return v if torch.is_tensor(v) else torch.stack(tuple(v))
         with torch.cuda.stream(self.copy_stream):
             self.copy_stream.wait_event(self.stage_free)          # the previous call has taken its data out of the staging buffers
             for k in ("x_ts", "x_static", "bin_ends", "y_multi", "y_multi_mask"):
-                self.stage[k].copy_(stacked(batch[k]), non_blocking=True)
+                self.stage[k].copy_(_stacked(batch[k]), non_blocking=True)
             self.stage["pixel_values"].copy_(next_batch["pixel_values"], non_blocking=True)
             self.h2d_done.record(self.copy_stream)
         self._staged = (id(batch), id(next_batch))
@@ -239,10 +266,85 @@ class GraphedTeacherStep:
             self._stage_h2d(next_batch, after_next)
         else:
             self._staged = None
-        self.opt.refresh_lrs()                       # learning rates of this step (scheduler) -> pinned descriptor table
-        self.g_fb.replay()
-        if self.g_opt is not None:
-            self._allreduce()
-            self.g_opt.replay()
-        self.opt.note_external_step()
-        return self.out
+        return self._replay()
+
+
+class GraphedStudentStep(_GraphedStep):
+    """`engine.train_student_batch` as captured graphs (engine.py:270-301; the loaders are all in "teacher" mode so one batch
+    feeds both models, trainer.py:890-895,923).  `pipeline_teacher=True`: the frozen teacher's forward for batch k+1 (CXR
+    encoder + its own frozen DuETT + fusion head, `main_logit` only) runs beside the student's step on batch k."""
+
+    def __init__(self, student, teacher, kd_loss_fn, optimizer, example_batch: dict, device, world: int = 1, group=None,
+                 warmup: int = 3, split: bool = False, before_capture=None, pipeline_teacher: bool = True):
+        if any(p.requires_grad for p in teacher.parameters()):
+            raise ValueError("the KD teacher must be frozen (trainer.py:856-865)")
+        self.student, self.teacher, self.loss_fn = student, teacher, kd_loss_fn
+        b = engine._move_lists(example_batch, device)
+        mk = lambda: {"x_ts": torch.stack(b["x_ts"]).contiguous(), "x_static": torch.stack(b["x_static"]).contiguous(),
+                      "bin_ends": torch.stack(b["bin_ends"]).contiguous(), "pixel_values": b["pixel_values"].clone()}
+        self.cur = mk()                                   # the batch the student trains on (and, unpipelined, the teacher reads)
+        self.nxt = mk() if pipeline_teacher else None     # the batch the teacher runs ahead on
+        self.y = b["y"].clone().float()
+        student.train()
+        teacher.eval()
+        with torch.no_grad():
+            self.z_cur = self._teacher_logit(self.cur).clone()
+        self.z_next = None
+        self._expect = None
+        self._setup(optimizer, device, world, group, split, pipeline_teacher, warmup, before_capture)
+
+    def _teacher_logit(self, bufs):
+        B = bufs["x_ts"].shape[0]
+        return self.teacher(tuple(bufs["x_ts"][i] for i in range(B)), tuple(bufs["x_static"][i] for i in range(B)),
+                            tuple(bufs["bin_ends"][i] for i in range(B)), bufs["pixel_values"])["main_logit"]
+
+    def _frozen_forward(self):
+        with torch.no_grad():
+            self.z_next = self._teacher_logit(self.nxt)
+
+    def _stateful_modules(self):
+        return [self.student, self.teacher]
+
+    def _hand_over(self):
+        if not self._captured:
+            self.z_next.record_stream(torch.cuda.current_stream(self.device))
+        self.z_cur.copy_(self.z_next)
+
+    def _train_fwd_bwd(self):
+        if not self.pipeline:
+            with torch.no_grad():
+                self.z_cur.copy_(self._teacher_logit(self.cur))
+        B = self.cur["x_ts"].shape[0]
+        z_s = self.student(tuple(self.cur["x_ts"][i] for i in range(B)), tuple(self.cur["x_static"][i] for i in range(B)),
+                           tuple(self.cur["bin_ends"][i] for i in range(B)))
+        losses = self.loss_fn(z_s, self.z_cur, self.y)
+        losses["total"].backward()
+        return {"loss": losses["total"].detach(), "bce": losses["bce"], "kd": losses["kd"], "logits": z_s.detach()}
+
+    @staticmethod
+    def _load(bufs, batch, with_pixels=True):
+        bufs["x_ts"].copy_(_stacked(batch["x_ts"]), non_blocking=True)
+        bufs["x_static"].copy_(_stacked(batch["x_static"]), non_blocking=True)
+        bufs["bin_ends"].copy_(_stacked(batch["bin_ends"]), non_blocking=True)
+        if with_pixels:
+            bufs["pixel_values"].copy_(batch["pixel_values"], non_blocking=True)
+
+    def prime(self, batch: dict) -> None:
+        """Pipelined mode: run the teacher for `batch` now (its logit was not produced by the previous replay)."""
+        self._load(self.nxt, batch)
+        with torch.no_grad():
+            self.z_cur.copy_(self._teacher_logit(self.nxt))
+        self._expect = id(batch)
+
+    def step(self, batch: dict | None = None, next_batch: dict | None = None) -> dict:
+        if batch is not None:
+            if self.pipeline and self._expect != id(batch):
+                self.prime(batch)
+            self._load(self.cur, batch, with_pixels=not self.pipeline)
+            self.y.copy_(batch["y"], non_blocking=True)
+        if self.pipeline:
+            nb = next_batch if next_batch is not None else batch
+            if nb is not None:
+                self._load(self.nxt, nb)
+                self._expect = id(nb)
+        return self._replay()

@@ -47,7 +47,16 @@ def make_scheduler(optimizer, total_steps: int, lr: float, warmup_steps: int = 3
 
 
 class FusedAdamW(torch.optim.Optimizer):
-    """Drop-in for `torch.optim.AdamW(param_groups, weight_decay=...)` (amsgrad / maximize unsupported)."""
+    """Drop-in for `torch.optim.AdamW(param_groups, weight_decay=...)` (amsgrad / maximize unsupported).
+
+    The kernel reads a device table of tensor descriptors (pointers, numel, lr, weight decay).  The host never rewrites
+    memory an in-flight copy or graph may still read: the table is built in a plain host array and goes to the device
+    through a RING of pinned staging buffers, each guarded by an event recorded behind its host->device copy (the host may
+    run several steps ahead of the GPU — bench.py reads the loss of step k-1, a training loop may never sync).  A captured
+    graph holds only the KERNEL node; the upload for replay k is enqueued on the stream right before the replay
+    (`refresh_lrs`), so replay k always sees the learning rates of step k."""
+
+    RING = 4
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
@@ -55,9 +64,21 @@ class FusedAdamW(torch.optim.Optimizer):
         self._chunk = lib().medp_adamw_chunk_elems()
         self._map_key = None
         self._blk_t = self._blk_c = self._descs_dev = None
-        self._descs_host = None
+        self._table = None            # host master copy of the descriptor table (ctypes array; the device never reads it)
+        self._ring, self._ring_ev, self._ring_n = [], [], 0
+        self._entries = []
         self.dev_step = None          # device uint32 step counter: bias corrections are computed ON DEVICE from it, so the
                                       # eager step and a captured-graph replay run bit-identical arithmetic
+
+    def _upload_table(self) -> None:
+        """master table -> next ring slot (after its previous copy has been consumed) -> device, stream-ordered."""
+        nbytes = ctypes.sizeof(self._table)
+        i = self._ring_n % self.RING
+        self._ring_n += 1
+        self._ring_ev[i].synchronize()                       # a no-op unless the GPU is >= RING uploads behind
+        ctypes.memmove(self._ring[i].data_ptr(), ctypes.addressof(self._table), nbytes)
+        self._descs_dev.copy_(self._ring[i], non_blocking=True)
+        self._ring_ev[i].record(torch.cuda.current_stream(self._descs_dev.device))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -86,8 +107,11 @@ class FusedAdamW(torch.optim.Optimizer):
             return loss
         self._step += 1
         dev = entries[0][0].device
+        capturing = torch.cuda.is_current_stream_capturing()
         key = tuple(p.numel() for p, *_ in entries)
         if key != self._map_key:
+            if capturing:
+                raise RuntimeError("FusedAdamW: the set of tensors changed inside a graph capture (run warm-up steps first)")
             bt, bc = [], []
             for i, n in enumerate(key):
                 nb = (n + self._chunk - 1) // self._chunk
@@ -95,16 +119,19 @@ class FusedAdamW(torch.optim.Optimizer):
                 bc += list(range(nb))
             self._blk_t = torch.tensor(bt, dtype=torch.int32, device=dev)
             self._blk_c = torch.tensor(bc, dtype=torch.int32, device=dev)
-            self._descs_host = torch.empty(len(key) * ctypes.sizeof(MedpAdamTensor), dtype=torch.uint8).pin_memory()
-            self._descs_dev = torch.empty_like(self._descs_host, device=dev)
+            self._table = (MedpAdamTensor * len(key))()
+            nbytes = ctypes.sizeof(self._table)
+            self._ring = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(self.RING)]
+            self._ring_ev = [torch.cuda.Event() for _ in range(self.RING)]
+            self._descs_dev = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             self._map_key = key
         self._entries = entries
-        arr = (MedpAdamTensor * len(entries)).from_address(self._descs_host.data_ptr())
         for i, (p, st, lr, wd) in enumerate(entries):
-            a = arr[i]
+            a = self._table[i]
             a.param, a.grad, a.exp_avg, a.exp_avg_sq = p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
             a.numel, a.lr, a.weight_decay = p.numel(), lr, wd
-        self._descs_dev.copy_(self._descs_host, non_blocking=True)
+        if not capturing:            # captured: only the kernel node is recorded; refresh_lrs() uploads before every replay
+            self._upload_table()
         if self.dev_step is None or self.dev_step.device != dev:
             self.dev_step = torch.full((1,), self._step - 1, dtype=torch.int32, device=dev)
         check(lib().medp_counter_advance(ptr(self.dev_step), stream()), "counter_advance")
@@ -115,12 +142,17 @@ class FusedAdamW(torch.optim.Optimizer):
         torch.autograd.graph.increment_version([p for p, *_ in entries])
         return loss
 
-    # ---- graph-replay support: the captured step re-uploads the pinned descriptor table; only the lr fields change ----
+    # ---- graph-replay support: the table captured with the step (its gradient pointers) + this step's learning rates ------
     def refresh_lrs(self) -> None:
+        """Call right before replaying a graph that captured `step()`, on the stream the replay is enqueued on."""
         lr_of = {id(p): float(g["lr"]) for g in self.param_groups for p in g["params"]}
-        arr = (MedpAdamTensor * len(self._entries)).from_address(self._descs_host.data_ptr())
         for i, (p, *_rest) in enumerate(self._entries):
-            arr[i].lr = lr_of[id(p)]
+            self._table[i].lr = lr_of[id(p)]
+        self._upload_table()
+
+    def current_lrs(self) -> list:
+        """Per-tensor learning rates of the table as last built (tests)."""
+        return [float(self._table[i].lr) for i in range(len(self._entries))]
 
     def note_external_step(self) -> None:
         """A captured replay updated the parameters: advance the host step count and the parameters' version counters."""

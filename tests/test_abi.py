@@ -52,3 +52,12 @@ def test_product_path_has_no_cpu_fallback():
     enc = CXREncoder("synthetic", config=Dinov2Cfg(hidden_size=128, num_hidden_layers=1, num_attention_heads=2, image_size=56))
     with pytest.raises(RuntimeError):
         enc(torch.zeros(1, 3, 56, 56))
+
+
+def test_cxr_encoder_raises_when_pretrained_weights_are_unavailable():
+    """Reference behaviour (model file :137): a missing checkpoint is an error, never a silent random initialisation."""
+    from multimodal_edema_prediction_amd.cxr import CXREncoder
+    with pytest.raises(RuntimeError, match="not available locally"):
+        CXREncoder("microsoft/rad-dino")
+    enc = CXREncoder("synthetic")                      # the synthetic benchmark's seeded random weights stay available
+    assert enc.d_out == 768

@@ -1,0 +1,25 @@
+"""`python bench.py --gpus N` as the driver invokes it (no RANK in the environment) must start one process per GPU under
+torch.distributed.run itself and relay rank 0's JSON line.  `--launch-check` does everything but the GPU work
+(gloo group, barrier, MAX-over-ranks exchange), so the launch / rendezvous / relay path is exercised here on CPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("n,extra", [(2, []), (3, ["--strong"]), (1, [])])
+def test_bench_self_launches_one_rank_per_gpu(n, extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--launch-check"] + extra,
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=170)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                      # exactly ONE JSON line on stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == n and out["value"] == float(n)          # MAX over ranks of (rank + 1): every rank took part
+    assert out["scaling"] == ("strong" if extra else "weak")

@@ -271,3 +271,36 @@ def test_graphed_step_equals_eager_step(tbatch):
         if a.requires_grad:
             assert float((a - b).abs().max()) <= 1e-6, k
     assert og._step == oe._step == 6
+
+
+def test_pathology_multilabel_loss_value_and_gradient():
+    """a14 (`PathologyMultiLabelLoss`, reference loss/losses_duett.py:63-125) on the HIP path: totals and per-label terms against
+    the fixture the reference's own class produced (`pml_total`, `pml_s2`, same logits: teacher_fwd_cfg1.npz), gradients of
+    both logit sets element-wise against the oracle's autograd (fp32 in, fp32 math: 1e-6), with and without pos_weight."""
+    from multimodal_edema_prediction_amd.losses_duett import PathologyMultiLabelLoss
+    from oracle import losses_ref
+    gold_f, gold_l = load_npz("teacher_fwd_cfg1.npz"), load_npz("teacher_loss_cfg1.npz")
+    y, mk = t(gold_l["y_multi"]), t(gold_l["y_multi_mask"])
+    s2 = t(gold_f["img_logits"]).to(DEV).requires_grad_(True)
+    s4 = t(gold_f["fusion_logits"]).to(DEV).requires_grad_(True)
+    out = PathologyMultiLabelLoss(torch.ones(K), None, 1.0, 0.5).to(DEV)(s2, s4, y.to(DEV), mk.to(DEV))
+    assert set(out) == {"total", "stage2_total", "stage4_total", "stage2_per", "stage4_per"}
+    assert abs(float(out["total"]) - float(gold_l["pml_total"])) <= 2e-6 * abs(float(gold_l["pml_total"])) + 1e-7
+    assert maxerr(out["stage2_per"], gold_l["pml_s2"]) < 1e-6
+    out["total"].backward()
+    for pw in (None, torch.linspace(0.5, 3.0, K)):
+        w = torch.linspace(0.5, 1.5, K)
+        a2, a4 = 0.7, 1.3
+        h2 = t(gold_f["img_logits"]).to(DEV).requires_grad_(True)
+        h4 = t(gold_f["fusion_logits"]).to(DEV).requires_grad_(True)
+        o = PathologyMultiLabelLoss(w, pw, a2, a4).to(DEV)(h2, h4, y.to(DEV), mk.to(DEV))
+        o["total"].backward()
+        r2 = t(gold_f["img_logits"]).clone().requires_grad_(True)
+        r4 = t(gold_f["fusion_logits"]).clone().requires_grad_(True)
+        ref = losses_ref.pathology_multilabel_loss(r2, r4, y, mk, w, pw, a2, a4)
+        ref["total"].backward()
+        assert abs(float(o["total"]) - float(ref["total"])) <= 2e-6 * abs(float(ref["total"]))
+        for k in ("stage2_total", "stage4_total", "stage2_per", "stage4_per"):
+            assert maxerr(o[k], ref[k]) < 2e-6, k
+        assert maxerr(h2.grad, r2.grad) < 1e-6 and maxerr(h4.grad, r4.grad) < 1e-6
+        assert float(r4.grad.abs().max()) > 1e-4          # the check is not vacuous

@@ -13,12 +13,10 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("split,vit_layers", [(False, None), (True, "0"), (True, "7"), (True, "4")])
-def test_pipelined_step_is_bit_identical(split, vit_layers, monkeypatch):
-    # vit_layers: how many encoder layers of the NEXT batch run in the forward/backward graph of the split (N > 1) step, the
-    # rest running beside the optimiser in the second graph (0: the whole encoder in the first graph)
-    if vit_layers is not None:
-        monkeypatch.setenv("MEDP_SPLIT_VIT_LAYERS", vit_layers)
+@pytest.mark.parametrize("split", [False, True])
+def test_pipelined_step_is_bit_identical(split):
+    # split=True is the N > 1 arrangement: forward/backward graph -> (all-reduce) -> optimiser graph on the main stream, the
+    # frozen encoder's graph for the next batch on its own stream beside them
     import test_gpu_model as T
     from multimodal_edema_prediction_amd.graph_step import GraphedTeacherStep
     from multimodal_edema_prediction_amd.losses_duett import DualPathologyLoss
@@ -38,7 +36,7 @@ def test_pipelined_step_is_bit_identical(split, vit_layers, monkeypatch):
         losses = [float(gs.step(batches[k], batches[n])["loss"].item()) for k, n in zip(order, announce)]
         return losses, {k: p.detach().clone() for k, p in te.named_parameters() if p.requires_grad}
 
-    l0, p0 = run(False)          # split=True is the N > 1 arrangement: separate forward/backward, optimiser and encoder graphs
+    l0, p0 = run(False)
     l1, p1 = run(True)
     np.testing.assert_array_equal(np.array(l1), np.array(l0))
     assert len(set(l0)) > 3                            # the batches really differ
@@ -76,3 +74,89 @@ def test_staged_host_batches_give_the_same_steps():
     np.testing.assert_array_equal(np.array(l1), np.array(l0))
     for k in p0:
         assert torch.equal(p0[k], p1[k]), k
+
+
+def test_graph_step_with_scheduler_matches_eager_without_host_sync():
+    """the learning-rate table must be the one of ITS step even when the host runs replays ahead of the GPU.
+    LinearLR warm-up changes the rate every step; the graph run enqueues all steps with no host sync in between and is compared
+    with the eager engine step (same arithmetic): per-step learning rates, losses and final parameters."""
+    import test_gpu_model as T
+    from multimodal_edema_prediction_amd import engine
+    from multimodal_edema_prediction_amd.graph_step import GraphedTeacherStep
+    from multimodal_edema_prediction_amd.losses_duett import DualPathologyLoss
+    from multimodal_edema_prediction_amd.optim import FusedAdamW, make_param_groups, make_scheduler
+    import warnings
+    warnings.filterwarnings("ignore", message=".*lr_scheduler.step.*")
+    dev = torch.device("cuda")
+    loss_fn = DualPathologyLoss(torch.ones(T.K), None, 0.5, 0.5, 1.0).to(dev)
+    batch = T.make_batch(T.CCFG, T.META["teacher_batch_start"], T.B, mode="teacher")
+    N, W = 12, 2
+    # W constant-rate steps first (the graph class's warm-up iterations are real steps), THEN the schedule starts in both runs
+    te = T.build_teacher()
+    oe = FusedAdamW(make_param_groups(te, 8e-3), weight_decay=5e-2)
+    for _ in range(W):
+        engine.train_teacher_dual_pathology_batch(batch, te, loss_fn, oe, dev)
+    se = make_scheduler(oe, total_steps=100, lr=8e-3, warmup_steps=10)
+    eager_loss, eager_lr = [], []
+    for _ in range(N):
+        eager_lr.append([g["lr"] for g in oe.param_groups])
+        eager_loss.append(engine.train_teacher_dual_pathology_batch(batch, te, loss_fn, oe, dev)["loss"])
+        se.step()
+    tg = T.build_teacher()
+    og = FusedAdamW(make_param_groups(tg, 8e-3), weight_decay=5e-2)
+    gs = GraphedTeacherStep(tg, loss_fn, og, batch, dev, warmup=W)
+    sg = make_scheduler(og, total_steps=100, lr=8e-3, warmup_steps=10)
+    graph_lr = []
+    stream_losses = torch.zeros(N, device=dev)
+    for i in range(N):                 # no .item(), no synchronize: the host runs ahead of the GPU
+        graph_lr.append([g["lr"] for g in og.param_groups])
+        stream_losses[i].copy_(gs.step(batch)["loss"])
+        sg.step()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(np.array(graph_lr), np.array(eager_lr), rtol=1e-12)
+    assert len({lr[-1] for lr in graph_lr}) == N                       # the rate really changed every step
+    np.testing.assert_allclose(stream_losses.cpu().numpy(), np.array(eager_loss), rtol=2e-5, atol=1e-6)
+    for (k, a), (_, b) in zip(te.named_parameters(), tg.named_parameters()):
+        if a.requires_grad:
+            assert float((a - b).abs().max()) <= 2e-6, k
+    assert og._step == oe._step == N + W
+
+
+def test_split_step_leaves_unused_parameters_alone():
+    """in the N > 1 arrangement (flat gradient arena) parameters that never receive a gradient — DuETT's SSL heads
+    when the backbone is trained inside the teacher — must stay untouched (no weight decay, no Adam state), exactly as in the
+    one-graph step; and both arrangements must train the used parameters identically."""
+    from multimodal_edema_prediction_amd.cohort import CohortCfg, make_batch
+    from multimodal_edema_prediction_amd.graph_step import GraphedTeacherStep
+    from multimodal_edema_prediction_amd.losses_duett import DualPathologyLoss
+    from multimodal_edema_prediction_amd.main_architecture_duett import (CXREncoder, PatchDualPathologyPerceiver, TeacherModel,
+                                                                           load_duett_backbone)
+    from multimodal_edema_prediction_amd.optim import FusedAdamW, make_param_groups
+    dev = torch.device("cuda")
+    Tn, V, DS, K, B = 32, 16, 8, 7, 4
+    batch = make_batch(CohortCfg(n_timesteps=Tn, n_vars=V, d_static=DS, image_size=224, n_labels=K), 0, B, mode="teacher")
+    loss_fn = DualPathologyLoss(torch.ones(K)).to(dev)
+
+    def run(split):
+        torch.manual_seed(0)
+        backbone = load_duett_backbone("synthetic", d_static_num=DS, d_time_series_num=V, n_timesteps=Tn, freeze=False)
+        cxr = CXREncoder("synthetic", freeze=True)
+        per = PatchDualPathologyPerceiver(K, backbone.d_representation, dropout=0.0, head_dropout=0.0)
+        te = TeacherModel(backbone, cxr, per, cxr_return_patches=True, d_img=768, use_aux_cxr=False, patch_dual_pathology_mode=True).to(dev)
+        before = {k: p.detach().clone() for k, p in te.named_parameters()}
+        opt = FusedAdamW(make_param_groups(te, 1e-3), weight_decay=5e-2)
+        gs = GraphedTeacherStep(te, loss_fn, opt, batch, dev, warmup=2, split=split, pipeline_cxr=True)
+        losses = [float(gs.step(batch, batch)["loss"].item()) for _ in range(3)]
+        return te, opt, before, losses, gs
+
+    te0, opt0, before0, l0, _ = run(False)
+    te1, opt1, before1, l1, gs1 = run(True)
+    unused = [k for k, p in te1.named_parameters() if p.requires_grad and (k.startswith("duett.head") or "pretrain_" in k or "predict_events" in k)]
+    assert unused and len(gs1.arena.unused) == len(unused)
+    named1 = dict(te1.named_parameters())
+    for k in unused:
+        assert torch.equal(named1[k], before1[k]), k            # untouched: no decay
+        assert named1[k].grad is None and len(opt1.state.get(named1[k], {})) == 0, k
+    np.testing.assert_allclose(l1, l0, rtol=1e-6)
+    for (k, a), (_, b) in zip(te0.named_parameters(), te1.named_parameters()):
+        assert float((a - b).abs().max()) <= 1e-6, k
