@@ -11,6 +11,7 @@ namespace {
 inline int grid_for(size_t work_items) { return (int)min((size_t)4096, max((size_t)1, (work_items + 255) / 256)); }
 
 // ---- grouped tiny linear: y[g][r][n] = b[g][n] + sum_k W[g][n][k] x[g][r][k]      (N*K <= 8192) ---------------------
+constexpr int GLINEAR_MAX_FLOATS = 36000;     // weights (+ bias) of one group held in LDS: 144 KB of the CU's 160 KB
 __global__ __launch_bounds__(256) void glinear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
                                                           float* __restrict__ y, int R, int K, int N) {
     extern __shared__ float sw[];            // N*K weights + N bias
@@ -282,7 +283,10 @@ int dw_chunks(int R) { return max(1, min(64, R / 96)); }
 }  // namespace
 
 extern "C" int medp_glinear_fwd(const float* x, const float* W, const float* b, float* y, int G, int R, int K, int N, void* stream) {
-    MEDP_CHECK_ARG(x && W && y && G > 0 && R > 0 && K > 0 && N > 0 && (size_t)N * K + N <= 16000, "glinear_fwd: bad argument");
+    MEDP_CHECK_ARG(x && W && y && G > 0 && R > 0 && K > 0 && N > 0 && (size_t)N * K + N <= GLINEAR_MAX_FLOATS, "glinear_fwd: bad argument");
+    MEDP_ONCE_PER_DEVICE({   // the per-pathology heads (256 -> 64) need 64.3 KB of weights in LDS: above the 64-KB default limit
+        (void)hipFuncSetAttribute((const void*)glinear_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GLINEAR_MAX_FLOATS * 4);
+    });
     glinear_fwd_kernel<<<dim3((R + 255) / 256, G), 256, ((size_t)N * K + N) * 4, (hipStream_t)stream>>>(x, W, b, y, R, K, N);
     MEDP_LAUNCH_CHECK("medp_glinear_fwd");
     return 0;
@@ -290,9 +294,12 @@ extern "C" int medp_glinear_fwd(const float* x, const float* W, const float* b, 
 extern "C" size_t medp_glinear_bwd_workspace_bytes(int G, int R, int K, int N) { return (size_t)G * dw_chunks(R) * ((size_t)N * K + N) * 4; }
 extern "C" int medp_glinear_bwd(const float* dy, const float* x, const float* W, float* dx, float* dW, float* db, float* workspace, int G,
                                 int R, int K, int N, void* stream) {
-    MEDP_CHECK_ARG(dy && x && W && G > 0 && R > 0 && K > 0 && N > 0 && (size_t)N * K <= 16000, "glinear_bwd: bad argument");
+    MEDP_CHECK_ARG(dy && x && W && G > 0 && R > 0 && K > 0 && N > 0 && (size_t)N * K <= GLINEAR_MAX_FLOATS, "glinear_bwd: bad argument");
     hipStream_t s = (hipStream_t)stream;
     if (dx) {
+        MEDP_ONCE_PER_DEVICE({
+            (void)hipFuncSetAttribute((const void*)glinear_bwd_dx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GLINEAR_MAX_FLOATS * 4);
+        });
         glinear_bwd_dx_kernel<<<dim3((R + 255) / 256, G), 256, (size_t)N * K * 4, s>>>(dy, W, dx, R, K, N);
         MEDP_LAUNCH_CHECK("medp_glinear_bwd(dx)");
     }

@@ -60,13 +60,13 @@ class _GraphedStep:
                 if self.split and self.arena is None:
                     # the first backward tells which parameters the step reaches; only those enter the arena
                     # (not a training step: module buffers — BatchNorm running statistics — and the dropout epoch are restored)
-                    bufs = [(b, b.detach().clone()) for m in self._stateful_modules() for b in m.buffers()]
+                    bufs = [(m, n, b.detach().clone()) for m in self._stateful_modules() for n, b in m.named_buffers()]
                     used = dp.find_used_parameters(self.params, lambda: (self._advance(), self._whole_fwd_bwd()))
                     self.arena = dp.FlatGradArena(self.params, used=used, group=group)
                     self.arena.bind(zero=True)
                     self.epoch.sub_(1)
-                    for b, saved in bufs:
-                        b.copy_(saved)
+                    for m, n, saved in bufs:               # by NAME: the training path may re-bind buffers (stacked BatchNorm statistics)
+                        m.get_buffer(n).copy_(saved)
                 self._zero_grads()
                 self._advance()
                 self._whole_fwd_bwd()

@@ -5,8 +5,11 @@ error behaviour, so `training_duett/{engine,trainer,evaluator}.
 (INTEGRATION.md shows the two-line module alias).  torch layers are parameter containers (identical state_dict keys and
 default initialisation order); all arithmetic is HIP through `autograd_ops` / the whole-module C calls.
 
-`TemporalPerceiver`, `PathologyPerceiver`, `DualPathologyPerceiver` are commented out in the reference at HEAD
-(model file :176-535, :659-741) and are deliberately absent here too: the reference trainer soft-imports them to None.
+`TemporalPerceiver` and `PathologyPerceiver` are commented out in the reference at HEAD (model file :176-535) and are
+deliberately absent here too: the reference trainer soft-imports them to None.  `DualPathologyPerceiver` (commented out
+too, :659-741) IS built: the reference's student entry point cannot run without it (trainer.py:770-822 rebuilds a `dual`
+teacher from `best.pt`) — restated from that source, pinned by a fixture the source itself produced
+(tests/golden/make_golden_dual.py).
 """
 from __future__ import annotations
 
@@ -21,8 +24,8 @@ from .cxr import CXREncoder, Dinov2Cfg  # noqa: F401  (re-exported)
 from .duett import DuettFeatureExtractor, load_duett_backbone  # noqa: F401  (re-exported)
 from .trajectory import LocalTrajectoryEncoder  # noqa: F401  (re-exported; model file :1242-1391)
 
-__all__ = ["DuettFeatureExtractor", "load_duett_backbone", "CXREncoder", "PatchDualPathologyPerceiver", "_PerceiverBlock",
-           "TeacherModel", "StudentModel"]
+__all__ = ["DuettFeatureExtractor", "load_duett_backbone", "CXREncoder", "PatchDualPathologyPerceiver", "DualPathologyPerceiver",
+           "_PerceiverBlock", "TeacherModel", "StudentModel"]
 
 # dropout stream ids (one per dropout site; combined with a per-forward seed)
 import os as _os
@@ -46,7 +49,7 @@ def _side_stream(device):
 
 
 _SID = {"img_cross": 0, "img_self": 10, "ts_cross": 20, "ts_self": 30, "image_head": 40, "temporal_head": 41,
-        "correction_head": 42, "student_head": 50}
+        "correction_head": 42, "residual_head": 43, "student_head": 50}
 
 
 class _BroadcastRowsFn(torch.autograd.Function):
@@ -199,6 +202,62 @@ class PatchDualPathologyPerceiver(nn.Module):
                          "{'full', 'hourly_only', 'rep_only'}")
 
 
+class DualPathologyPerceiver(nn.Module):
+    """Mirror of the reference's `DualPathologyPerceiver` (model file :659-741, commented out at HEAD; the student entry point
+    needs it): image branch = K logits of a frozen pretrained CXR head, injected by TeacherModel; temporal branch = pathology
+    queries x ts tokens (cross + self block) -> one MLP head per pathology for the TS-only logits and one for the residual;
+    `fusion_logit[k] = img_logit[k] + residual_head_k(T[:, k])`.  The 2K per-pathology heads run as TWO grouped launches each
+    (group = pathology) instead of 2K x 2 small Linears."""
+
+    def __init__(self, n_pathologies: int, d_ts: int, d_latent: int = 256, n_heads: int = 4, dropout: float = 0.1,
+                 head_hidden: int = 64, head_dropout: float = 0.1):
+        super().__init__()
+        self.n_pathologies = n_pathologies
+        self.d_latent = d_latent
+        self.temporal_queries = nn.Parameter(torch.randn(n_pathologies, d_latent) * 0.02)
+        self.ts_proj = nn.Linear(d_ts, d_latent)
+        self.ts_cross = _PerceiverBlock(d_latent, n_heads, dropout)
+        self.ts_self = _PerceiverBlock(d_latent, n_heads, dropout)
+        self.ts_cross._sid, self.ts_self._sid = _SID["ts_cross"], _SID["ts_self"]
+
+        def _mk_head():
+            return nn.Sequential(nn.Linear(d_latent, head_hidden), nn.GELU(), nn.Dropout(head_dropout), nn.Linear(head_hidden, 1))
+
+        self.temporal_heads = nn.ModuleList([_mk_head() for _ in range(n_pathologies)])
+        self.residual_heads = nn.ModuleList([_mk_head() for _ in range(n_pathologies)])
+
+    def _grouped_heads(self, T_kbd, heads, seed, sid):
+        """T_kbd [K, B, d] -> [B, K]: head k on rows of pathology k."""
+        from .duett_train import AxisSwapFn, GLinearFn
+        K, B, _ = T_kbd.shape
+        p = float(heads[0][2].p) if heads[0][2].training else 0.0
+        h = GLinearFn.apply(T_kbd, torch.stack([m[0].weight for m in heads]), torch.stack([m[0].bias for m in heads]))
+        h = A.gelu_dropout(h, p, seed, sid)
+        z = GLinearFn.apply(h, torch.stack([m[3].weight for m in heads]), torch.stack([m[3].bias for m in heads]))     # [K, B, 1]
+        return AxisSwapFn.apply(z.view(1, K, B, 1)).view(B, K)
+
+    def forward(self, ts_tokens, img_logits, return_attn: bool = False, ts_ablation: str = "hourly_only") -> dict:
+        from .duett_train import AddBcastFn, AxisSwapFn
+        ts_selected = PatchDualPathologyPerceiver._select_ts(self, ts_tokens, ts_ablation)
+        B = ts_tokens.size(0)
+        seed = A.next_seed() if self.training else 0
+        ts_kv = A.linear(ts_selected, self.ts_proj.weight, self.ts_proj.bias)
+        q0 = _BroadcastRowsFn.apply(self.temporal_queries, B)
+        T_tok, ts_attn = self.ts_cross(q0, ts_kv, True, _shared_q=self.temporal_queries, _seed=seed) if return_attn else \
+            (self.ts_cross(q0, ts_kv, _shared_q=self.temporal_queries, _seed=seed), None)
+        T_tok = self.ts_self(T_tok, T_tok, _seed=seed)                                   # [B, K, d]
+        K, d = T_tok.shape[1], T_tok.shape[2]
+        T_kbd = AxisSwapFn.apply(T_tok.reshape(1, B, K, d)).view(K, B, d)
+        ts_logits = self._grouped_heads(T_kbd, self.temporal_heads, seed, _SID["temporal_head"])
+        residuals = self._grouped_heads(T_kbd, self.residual_heads, seed, _SID["residual_head"])
+        fusion_logits = AddBcastFn.apply(residuals, img_logits.detach().view(B, K, 1).reshape(B, K))   # img_logits: passthrough, no gradient
+        out = {"img_logits": img_logits, "ts_logits": ts_logits, "fusion_logits": fusion_logits, "ts_tokens": T_tok,
+               "residuals": residuals}
+        if return_attn:
+            out["ts_attn"] = ts_attn
+        return out
+
+
 class TeacherModel(nn.Module):
     """Mirror of model file :993-1197.  The live configuration (`patch_dual_pathology_mode=True`, run_duett.sh:8) is built;
     the other modes need perceiver classes that are commented out in the reference and raise here."""
@@ -231,11 +290,48 @@ class TeacherModel(nn.Module):
             if use_aux_cxr:
                 self.aux_cxr_head = nn.Sequential(nn.Linear(d, aux_head_hidden), nn.GELU(), nn.Dropout(head_dropout),
                                                   nn.Linear(aux_head_hidden, 1))
-        if dual_pathology_mode:
+        if dual_pathology_mode:                                             # model file :1047-1071
             if pretrained_cxr_head_ckpt is None or pathology_labels is None:
                 raise ValueError("dual_pathology_mode requires pretrained_cxr_head_ckpt AND pathology_labels")
-            raise NotImplementedError("dual_pathology_mode needs DualPathologyPerceiver, which is commented out in the reference "
-                                      "at HEAD (model file :659-741); SURVEY.md §8f-2")
+            # the linear-probe checkpoint (cxr_linear_training.ipynb :827-845) is plain data: loaded without unpickling code
+            state = torch.load(pretrained_cxr_head_ckpt, map_location="cpu", weights_only=True)
+            num_pretrained = int(state["num_classes"])
+            pretrained_labels = list(state["label_cols"])
+            missing = [lbl for lbl in pathology_labels if lbl not in pretrained_labels]
+            if missing:
+                raise ValueError(f"pathology_labels missing from the pretrained CXR head: {missing}. pretrained labels: {pretrained_labels}")
+            keep_idx = [pretrained_labels.index(lbl) for lbl in pathology_labels]
+            self.pretrained_cxr_head = nn.Linear(d_img, num_pretrained)
+            clf_sd = state["classifier_state_dict"]
+            self.pretrained_cxr_head.load_state_dict({"weight": clf_sd["1.weight"], "bias": clf_sd["1.bias"]})
+            for p in self.pretrained_cxr_head.parameters():
+                p.requires_grad = False
+            self.register_buffer("cxr_head_keep_idx", torch.tensor(keep_idx, dtype=torch.long))
+
+    def _dual_forward(self, duett_in, pixel_values, return_attn):
+        """model file :1132-1150: CLS -> frozen pretrained head -> the K kept columns -> DualPathologyPerceiver.  Only the kept
+        rows of the head are multiplied (the same numbers as computing all C columns and gathering K of them)."""
+        ts_tokens = self.duett.encode(duett_in)
+        cls = self.cxr(pixel_values)
+        if isinstance(cls, tuple):
+            cls = cls[0]
+        with torch.no_grad():
+            head = self.pretrained_cxr_head
+            K = self.cxr_head_keep_idx.numel()
+            key = (head.weight.data_ptr(), head.weight._version, head.bias._version, self.cxr_head_keep_idx._version)
+            if getattr(self, "_kept_head", (None,))[0] != key:
+                Kp = (K + 3) // 4 * 4                                       # the GEMM wants N in multiples of 4: zero rows appended
+                W, b = head.weight.new_zeros((Kp, head.in_features)), head.bias.new_zeros(Kp)
+                W[:K], b[:K] = head.weight[self.cxr_head_keep_idx], head.bias[self.cxr_head_keep_idx]
+                self._kept_head = (key, W, b)
+            _, W, b = self._kept_head
+            img_logits = A.linear(cls.contiguous(), W, b)[:, :K].contiguous()
+        out = self.perceiver(ts_tokens, img_logits, return_attn=return_attn)
+        result = {"main_logit": out["fusion_logits"][:, 0], "img_logits": out["img_logits"], "ts_logits": out["ts_logits"],
+                  "fusion_logits": out["fusion_logits"]}
+        if return_attn:
+            result["ts_tokens"], result["ts_attn"], result["residuals"] = out["ts_tokens"], out["ts_attn"], out["residuals"]
+        return result
 
     def forward(self, x_ts_list, x_static_list, bin_ends_list, pixel_values: torch.Tensor, batch_size: Optional[int] = None,
                 return_attn: bool = False, *, _cxr_tokens16: Optional[torch.Tensor] = None):
@@ -244,9 +340,12 @@ class TeacherModel(nn.Module):
         if batch_size is None:
             batch_size = pixel_values.shape[0]
         x = (x_ts_list, x_static_list, bin_ends_list)
-        if not self.patch_dual_pathology_mode:
-            raise NotImplementedError("only patch_dual_pathology_mode is live in the reference at HEAD (SURVEY.md F6)")
+        if not (self.patch_dual_pathology_mode or self.dual_pathology_mode):
+            raise NotImplementedError("only the patch_dual (live at HEAD) and dual (needed by the student entry point) perceiver modes "
+                                      "are built (SURVEY.md F6, 8(f2))")
         duett_in = self.duett.feats_to_input(x, batch_size)
+        if self.dual_pathology_mode:
+            return self._dual_forward(duett_in, pixel_values, return_attn)
         pc = self.perceiver
         B = pixel_values.shape[0]
         seed = A.next_seed() if pc.training else 0

@@ -103,3 +103,57 @@ def teacher_fusion_forward(sd, ts_tokens, img_patches, n_heads=4, **kw):
         for k in ("img_tokens", "ts_tokens", "fusion_tokens", "img_attn", "ts_attn"):
             res[k] = out[k]
     return res
+
+
+def dual_perceiver_forward(sd, ts_tokens, img_logits, n_heads=4, p="", dropout=0.0, head_dropout=0.0, training=False,
+                           return_attn=False, ts_ablation="hourly_only"):
+    """`DualPathologyPerceiver.forward` — commented out at the reference's HEAD (model file `:659-741`) but required by its
+    student entry point (`training_duett/trainer.py:770-822`): temporal queries x ts tokens (cross + self block), one MLP head per
+    pathology for the TS-only logits and one for the residual, `fusion = img_logits + residuals` (img_logits come from the frozen
+    pretrained CXR head and carry no gradient).  Pinned by tests/golden/teacher_dual_cfg1.npz, produced by executing the
+    reference's own (un-commented) text."""
+    B = ts_tokens.size(0)
+    if ts_ablation == "full":
+        sel = ts_tokens
+    elif ts_ablation == "hourly_only":
+        sel = ts_tokens[:, :-1, :]
+    elif ts_ablation == "rep_only":
+        sel = ts_tokens[:, -1:, :]
+    else:
+        raise ValueError(f"unknown ts_ablation={ts_ablation!r}; expected one of "
+                         "{'full', 'hourly_only', 'rep_only'}")
+    ts_kv = F.linear(sel, sd[p + "ts_proj.weight"], sd[p + "ts_proj.bias"])
+    q = sd[p + "temporal_queries"].unsqueeze(0).expand(B, -1, -1)
+    blk = lambda lat, kv, name, ra=False: perceiver_block(lat, kv, sd, p + name + ".", n_heads, dropout, training, ra)
+    T, ts_attn = blk(q, ts_kv, "ts_cross", True) if return_attn else (blk(q, ts_kv, "ts_cross"), None)
+    T = blk(T, T, "ts_self")
+    K = T.shape[1]
+
+    def heads(name):
+        cols = []
+        for k in range(K):
+            h = F.gelu(F.linear(T[:, k], sd[f"{p}{name}.{k}.0.weight"], sd[f"{p}{name}.{k}.0.bias"]))
+            h = F.dropout(h, head_dropout, training)
+            cols.append(F.linear(h, sd[f"{p}{name}.{k}.3.weight"], sd[f"{p}{name}.{k}.3.bias"]).squeeze(-1))
+        return torch.stack(cols, dim=1)
+
+    ts_logits, residuals = heads("temporal_heads"), heads("residual_heads")
+    out = {"img_logits": img_logits, "ts_logits": ts_logits, "fusion_logits": img_logits + residuals, "ts_tokens": T,
+           "residuals": residuals}
+    if return_attn:
+        out["ts_attn"] = ts_attn
+    return out
+
+
+def teacher_dual_forward(sd, ts_tokens, cls, n_heads=4, **kw):
+    """`TeacherModel.forward`, dual branch (model file `:1132-1150`): CLS -> frozen pretrained linear CXR head -> the K kept
+    columns (`cxr_head_keep_idx`, `:1047-1071`) -> `DualPathologyPerceiver`."""
+    with torch.no_grad():
+        pre = F.linear(cls, sd["pretrained_cxr_head.weight"], sd["pretrained_cxr_head.bias"])
+    img_logits = pre[:, sd["cxr_head_keep_idx"]]
+    out = dual_perceiver_forward(sd, ts_tokens, img_logits, n_heads, p="perceiver.", **kw)
+    res = {"main_logit": out["fusion_logits"][:, 0], "img_logits": out["img_logits"], "ts_logits": out["ts_logits"],
+           "fusion_logits": out["fusion_logits"]}
+    if kw.get("return_attn"):
+        res["ts_tokens"], res["ts_attn"], res["residuals"] = out["ts_tokens"], out["ts_attn"], out["residuals"]
+    return res

@@ -1,7 +1,9 @@
-"""BASELINE metric, second half: "AUROC parity vs CPU ref".  The same teacher (same weights) is TRAINED for a few dozen
-steps on a learnable synthetic cohort twice — by the HIP engine step (bf16 MFMA operands, fused AdamW) and by the fp32 CPU
-oracle step — and both models then score the same held-out items.  Stated tolerances: held-out fusion logits correlate
-> 0.98, per-label AUROC differs by < 0.05, mean AUROC by < 0.03 (48 held-out items: one swapped pair moves an AUROC by ~0.004)."""
+"""BASELINE metric, second half: "AUROC parity vs CPU ref" — the experiment SURVEY.md §8(d) / BASELINE.md §3 define: the same
+teacher (same weights) is TRAINED for 200 identical steps (dropout / augmentation off) on a learnable synthetic cohort twice —
+by the HIP engine step (bf16 MFMA operands, fused AdamW) and by the fp32 CPU oracle step — and both models then score the same
+512 held-out items.  Contract tolerances, asserted as written there: per-label AUROC within 0.005, macro AUROC within 0.003.
+The frozen encoders' tokens of the oracle side are computed ONCE per batch on the CPU (by the oracle's own encoders) and reused
+over the 200 steps — they do not change — and the images are 112x112 (65 ViT tokens) so that the CPU side stays in budget."""
 import os
 import sys
 
@@ -24,8 +26,8 @@ def test_trained_teacher_auroc_matches_cpu_oracle():
     from oracle.step_ref import split_teacher_sd
 
     dev = torch.device("cuda")
-    T, V, DS, K, B = 32, 16, 8, 7, 8
-    n_train_b, n_eval_b, n_steps, lr = 6, 6, 30, 1e-3
+    T, V, DS, K, B, IMG = 32, 16, 8, 7, 16, 112
+    n_train_b, n_eval_b, n_steps, lr = 16, 32, 200, 5e-4          # 256 training items cycled, 512 held-out items
     torch.manual_seed(0)
     backbone = load_duett_backbone("synthetic", d_static_num=DS, d_time_series_num=V, n_timesteps=T, freeze=True)
     cxr = CXREncoder("synthetic", freeze=True)
@@ -34,7 +36,8 @@ def test_trained_teacher_auroc_matches_cpu_oracle():
     teacher = TeacherModel(backbone, cxr, per, cxr_return_patches=True, d_img=768, use_aux_cxr=False,
                            patch_dual_pathology_mode=True).to(dev)
     sd = {k: v.detach().float().cpu().clone() for k, v in teacher.state_dict().items()}
-    ccfg = CohortCfg(n_timesteps=T, n_vars=V, d_static=DS, image_size=224, n_labels=K, learnable=True)
+    ccfg = CohortCfg(n_timesteps=T, n_vars=V, d_static=DS, image_size=IMG, n_labels=K, learnable=True)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     train_b = [make_batch(ccfg, i * B, B, mode="teacher") for i in range(n_train_b)]
     eval_b = [make_batch(ccfg, 10_000 + i * B, B, mode="teacher") for i in range(n_eval_b)]
 
@@ -93,8 +96,9 @@ def test_trained_teacher_auroc_matches_cpu_oracle():
     # ---- parity ------------------------------------------------------------------------------------------------------
     assert ref_losses[-1] < ref_losses[0]                                  # it does train
     np.testing.assert_allclose(hip_losses, ref_losses, rtol=3e-2, atol=2e-2)
+    assert np.mean(ref_losses[-16:]) < 0.9 * np.mean(ref_losses[:16])       # a real training run, not a flat line
     corr = float(np.corrcoef(hip_logits.ravel(), ref_logits.ravel())[0, 1])
-    assert corr > 0.98, corr
+    assert corr > 0.995, corr
     y = torch.cat([b["y_multi"] for b in eval_b]).numpy()
     mk = torch.cat([b["y_multi_mask"] for b in eval_b]).numpy() > 0
     a_hip, a_ref = [], []
@@ -104,6 +108,8 @@ def test_trained_teacher_auroc_matches_cpu_oracle():
             continue
         a_hip.append(evaluator.auroc(yy, hip_logits[mk[:, k], k]))
         a_ref.append(evaluator.auroc(yy, ref_logits[mk[:, k], k]))
-    assert len(a_hip) >= 3
-    assert max(abs(a - b) for a, b in zip(a_hip, a_ref)) < 0.05, (a_hip, a_ref)
-    assert abs(float(np.mean(a_hip)) - float(np.mean(a_ref))) < 0.03, (a_hip, a_ref)
+    print("per-label AUROC hip", np.round(a_hip, 4), "oracle", np.round(a_ref, 4), "max |logit diff|", float(np.abs(hip_logits - ref_logits).max()))
+    assert len(a_hip) == K and len(y) == 512
+    assert float(np.mean(a_ref)) > 0.6                                       # the cohort is learnable and was learnt
+    assert max(abs(a - b) for a, b in zip(a_hip, a_ref)) <= 0.005, (a_hip, a_ref)               # BASELINE.md §3 / SURVEY §8(d)
+    assert abs(float(np.mean(a_hip)) - float(np.mean(a_ref))) <= 0.003, (a_hip, a_ref)
