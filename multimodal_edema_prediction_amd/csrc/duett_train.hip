@@ -180,22 +180,34 @@ __global__ __launch_bounds__(256) void embed_inputs_fwd_kernel(const float* __re
         for (int k = 2; k < KP; ++k) o[k] = 0.f;
     }
 }
-// d_table partials: each block accumulates its elements' d_xin[...,1] into 16 LDS bins (LDS atomics: exact order within a
-// block is irrelevant to the bins' values up to fp32 rounding; the cross-block sum is a deterministic column sum)
+// d_table partials: every thread keeps 16 private bins over ITS elements (a fixed assignment), the bins are then summed over the
+// wave with the fixed shuffle tree and over the four waves in a fixed order — bitwise reproducible (LDS float atomics, the
+// first form of this kernel, are not: their order across waves varies from launch to launch, and AdamW turns a last-bit
+// difference of a near-zero gradient into a full-size step).  The cross-block sum is a deterministic column sum.
 __global__ __launch_bounds__(256) void embed_inputs_bwd_kernel(const float* __restrict__ xs, const float* __restrict__ dxin, float* __restrict__ partial,
                                                                int nrows_table, int B, int T, int V, int KP) {
-    __shared__ float bins[64];
-    if (threadIdx.x < 64) bins[threadIdx.x] = 0.f;
-    __syncthreads();
+    constexpr int NB = 16;                       // n_obs_embedding has 16 rows (duett.py:88); checked by the launcher
+    __shared__ float red[4][NB];
+    float bins[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) bins[k] = 0.f;
     const size_t n = (size_t)V * B * T;
     const int F = 2 * V + 1;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const int r = (int)(i % ((size_t)B * T)), v = (int)(i / ((size_t)B * T));
         const int idx = min(max((int)xs[(size_t)r * F + V + v], 0), nrows_table - 1);
-        atomicAdd(&bins[idx], dxin[i * KP + 1]);
+        const float g = dxin[i * KP + 1];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) bins[k] += idx == k ? g : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const float w = wave_sum(bins[k]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = w;
     }
     __syncthreads();
-    if (threadIdx.x < nrows_table) partial[(size_t)blockIdx.x * nrows_table + threadIdx.x] = bins[threadIdx.x];
+    if (threadIdx.x < nrows_table)
+        partial[(size_t)blockIdx.x * nrows_table + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // ---- psi assembly (model :53-66) and its backward -------------------------------------------------------------------------
@@ -229,29 +241,41 @@ __global__ __launch_bounds__(256) void psi_assemble_fwd_kernel(const float* __re
 __global__ __launch_bounds__(256) void psi_assemble_bwd_kernel(const float* __restrict__ xs, const float* __restrict__ dpsi, float* __restrict__ d_var,
                                                                float* __restrict__ d_tab, float* __restrict__ d_special_part, int B, int T, int V,
                                                                int E) {
-    extern __shared__ float acc[];          // [3][E]: tab, special0, special1
+    // Deterministic: pass 1 scatters d_var and records each cell's kind; pass 2 gives every (kind, e) sum to ONE thread, which
+    // walks the batch element's cells in index order (the sums are 3 x E values over (T+1)(V+1) cells: tiny).
+    extern __shared__ unsigned char kinds[];          // [(T+1)*(V+1)]
     const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < 3 * E; i += 256) acc[i] = 0.f;
-    __syncthreads();
     const int cells = (T + 1) * (V + 1);
     for (int cidx = threadIdx.x; cidx < cells; cidx += 256) {
         const int t = cidx / (V + 1), v = cidx % (V + 1);
         const int kind = psi_cell_kind(xs, b, t, v, T, V);
-        const float* g = dpsi + (((size_t)b * (T + 1) + t) * (V + 1) + v) * E;
+        kinds[cidx] = (unsigned char)kind;
         if (v < V && t < T) {
+            const float* g = dpsi + (((size_t)b * (T + 1) + t) * (V + 1) + v) * E;
             float* o = d_var + (((size_t)v * B + b) * T + t) * E;
             for (int e = 0; e < E; ++e) o[e] = kind == 0 ? g[e] : 0.f;
         }
-        if (kind != 0) {
-            float* a = acc + (kind - 1) * E;
-            for (int e = 0; e < E; ++e) atomicAdd(&a[e], g[e]);
-        }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < E; e += 256) {
-        d_tab[(size_t)b * E + e] = acc[e];
-        d_special_part[((size_t)b * 2 + 0) * E + e] = acc[E + e];
-        d_special_part[((size_t)b * 2 + 1) * E + e] = acc[2 * E + e];
+    // 3*E sums, each split over `parts` threads by cell-index stripes, combined in a fixed order through LDS
+    const int nsum = 3 * E, parts = 256 / nsum > 0 ? 256 / nsum : 1;
+    __shared__ float partial[256];
+    const int id = threadIdx.x;
+    float a = 0.f;
+    if (id < nsum * parts) {
+        const int sidx = id % nsum, part = id / nsum, kind = sidx / E + 1, e = sidx % E;
+        const float* base = dpsi + (size_t)b * cells * E + e;
+        for (int cidx = part; cidx < cells; cidx += parts)
+            if (kinds[cidx] == kind) a += base[(size_t)cidx * E];
+    }
+    partial[id] = a;
+    __syncthreads();
+    if (id < nsum) {
+        float tot = 0.f;
+        for (int part = 0; part < parts; ++part) tot += partial[part * nsum + id];
+        const int kind = id / E, e = id % E;
+        if (kind == 0) d_tab[(size_t)b * E + e] = tot;
+        else d_special_part[((size_t)b * 2 + (kind - 1)) * E + e] = tot;
     }
 }
 
@@ -367,7 +391,7 @@ extern "C" int medp_embed_inputs_fwd(const float* xs_ts, const float* n_obs_tabl
 extern "C" int medp_embed_inputs_bwd_blocks(int B, int T, int V) { return min(256, grid_for((size_t)V * B * T)); }
 extern "C" int medp_embed_inputs_bwd(const float* xs_ts, const float* d_xin, float* partial /*[blocks][table_rows]*/, int table_rows, int B, int T,
                                      int V, int KP, void* stream) {
-    MEDP_CHECK_ARG(xs_ts && d_xin && partial && table_rows > 0 && table_rows <= 64, "embed_inputs_bwd: bad argument");
+    MEDP_CHECK_ARG(xs_ts && d_xin && partial && table_rows > 0 && table_rows <= 16, "embed_inputs_bwd: bad argument (the n_obs table has at most 16 rows)");
     embed_inputs_bwd_kernel<<<medp_embed_inputs_bwd_blocks(B, T, V), 256, 0, (hipStream_t)stream>>>(xs_ts, d_xin, partial, table_rows, B, T, V, KP);
     MEDP_LAUNCH_CHECK("medp_embed_inputs_bwd");
     return 0;
@@ -381,8 +405,9 @@ extern "C" int medp_psi_assemble_fwd(const float* xs_ts, const float* var_out, c
 }
 extern "C" int medp_psi_assemble_bwd(const float* xs_ts, const float* dpsi, float* d_var_out, float* d_tab_out, float* d_special_partial /*[B][2][E]*/,
                                      int B, int T, int V, int E, void* stream) {
-    MEDP_CHECK_ARG(xs_ts && dpsi && d_var_out && d_tab_out && d_special_partial, "psi_assemble_bwd: bad argument");
-    psi_assemble_bwd_kernel<<<B, 256, 3 * E * sizeof(float), (hipStream_t)stream>>>(xs_ts, dpsi, d_var_out, d_tab_out, d_special_partial, B, T, V, E);
+    MEDP_CHECK_ARG(xs_ts && dpsi && d_var_out && d_tab_out && d_special_partial && E > 0 && 3 * E <= 256 && (T + 1) * (V + 1) <= 60000,
+                   "psi_assemble_bwd: bad argument");
+    psi_assemble_bwd_kernel<<<B, 256, (size_t)(T + 1) * (V + 1), (hipStream_t)stream>>>(xs_ts, dpsi, d_var_out, d_tab_out, d_special_partial, B, T, V, E);
     MEDP_LAUNCH_CHECK("medp_psi_assemble_bwd");
     return 0;
 }

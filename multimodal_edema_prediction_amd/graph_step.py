@@ -18,13 +18,18 @@ forward/backward and one update; results are bit-identical to the unpipelined st
 
 One GPU: ONE graph holds all of it (three parallel branches).  N > 1 (`split`): gradients accumulate into a flat fp32
 arena (dp.FlatGradArena: only parameters that really receive a gradient, the others keep `.grad = None` as under DDP's
-find_unused_parameters) and the step is three graphs on two streams:
-      main stream :  [forward/backward graph] -> RCCL mean all-reduce of the arena -> [optimiser graph]
-      frozen stream: [frozen-forward graph of batch k+1] .............................................. join
-so the collective (14.8 MB teacher / 35.6 MB student) and the update run UNDER the frozen encoder's GEMMs of the next batch —
-the long pole of the step — instead of between two serial graphs.  No collective is captured into a graph.
+find_unused_parameters) and the step is
+      [forward/backward graph (+ the frozen forward of batch k+1 as a parallel branch)] -> RCCL mean all-reduce -> [optimiser graph]
+with ONE collective over the whole arena (14.8 MB teacher / 35.6 MB student: latency-bound on xGMI, so one large message).
+No collective is captured into a graph.  Measured alternatives (one GPU, size-1 RCCL group, `bench.py` with MEDP_FORCE_PG=1;
+DESIGN.md §7): the frozen forward as its OWN graph on its own stream beside the other two graphs, so that collective and update
+would hide under the encoder's GEMMs, ran 23 % SLOWER (8.96 k against 11.67 k samples/s): graphs launched on different streams
+execute back to back on this runtime, they do not overlap; every extra graph boundary costs ~0.15-0.2 ms, more than the
+collective it could hide.  Hence the fewest boundaries: two graphs, the collective between them.
 """
 from __future__ import annotations
+
+import os
 
 import torch
 
@@ -77,7 +82,7 @@ class _GraphedStep:
         self._zero_grads()
         if before_capture is not None:
             before_capture()
-        self.g_frozen = self.g_opt = None
+        self.g_opt = None
         self.g_fb = torch.cuda.CUDAGraph()
         if not self.split:
             with torch.cuda.graph(self.g_fb):
@@ -85,17 +90,17 @@ class _GraphedStep:
                 self.out = self._whole_fwd_bwd()
                 self.opt.step()
         else:
-            if self.pipeline:
-                self.g_frozen = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.g_frozen):
-                    self._frozen_forward()
             with torch.cuda.graph(self.g_fb):
                 self.arena.flat.zero_()
                 self._advance()
-                self.out = self._train_fwd_bwd()
-            self.g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_opt):
-                self.opt.step()
+                self.out = self._whole_fwd_bwd()
+            # the update after the collective is two launches over fixed buffers (the arena views never move): issued directly
+            # (`FusedAdamW.relaunch`) rather than as a second graph — one graph boundary less per step.  MEDP_SPLIT_OPT=graph
+            # keeps the two-graph form for A/B runs.
+            if os.environ.get("MEDP_SPLIT_OPT", "eager") == "graph":
+                self.g_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_opt):
+                    self.opt.step()
         torch.cuda.synchronize(device)
         self._captured = True
         self.opt._step = int(self.opt.dev_step.item())      # capture ran opt.step() on the host without executing it
@@ -128,23 +133,18 @@ class _GraphedStep:
         return out
 
     def _replay(self):
-        """refresh_lrs + the graphs of one step, on the current stream (+ the frozen stream when split and pipelined)."""
-        cur = torch.cuda.current_stream(self.device)
+        """refresh_lrs + the graph(s) of one step on the current stream."""
         self.opt.refresh_lrs()                       # this step's learning rates -> device table, ahead of the replay
-        if self.g_opt is None:
-            self.g_fb.replay()
-        else:
-            if self.g_frozen is not None:
-                self.frozen_stream.wait_stream(cur)  # the next batch's inputs were loaded on the main stream
-                with torch.cuda.stream(self.frozen_stream):
-                    self.g_frozen.replay()
-            self.g_fb.replay()
-            self._allreduce()                        # RCCL on its own stream, ordered after g_fb; runs under g_frozen
+        self.g_fb.replay()
+        if not self.split:
+            self.opt.note_external_step()
+            return self.out
+        self._allreduce()                            # RCCL on its own stream, ordered after g_fb by the process group
+        if self.g_opt is not None:
             self.g_opt.replay()
-            if self.g_frozen is not None:
-                cur.wait_stream(self.frozen_stream)
-                self._hand_over()
-        self.opt.note_external_step()
+            self.opt.note_external_step()
+        else:
+            self.opt.relaunch()
         return self.out
 
 
@@ -279,6 +279,8 @@ class GraphedStudentStep(_GraphedStep):
         if any(p.requires_grad for p in teacher.parameters()):
             raise ValueError("the KD teacher must be frozen (trainer.py:856-865)")
         self.student, self.teacher, self.loss_fn = student, teacher, kd_loss_fn
+        import inspect
+        self._teacher_kw = set(inspect.signature(teacher.forward).parameters)      # a stand-in teacher (tests) may lack the private switch
         b = engine._move_lists(example_batch, device)
         mk = lambda: {"x_ts": torch.stack(b["x_ts"]).contiguous(), "x_static": torch.stack(b["x_static"]).contiguous(),
                       "bin_ends": torch.stack(b["bin_ends"]).contiguous(), "pixel_values": b["pixel_values"].clone()}
@@ -293,14 +295,16 @@ class GraphedStudentStep(_GraphedStep):
         self._expect = None
         self._setup(optimizer, device, world, group, split, pipeline_teacher, warmup, before_capture)
 
-    def _teacher_logit(self, bufs):
+    def _teacher_logit(self, bufs, forked: bool = False):
         B = bufs["x_ts"].shape[0]
+        kw = {"_overlap": False} if (forked and "_overlap" in self._teacher_kw) else {}
         return self.teacher(tuple(bufs["x_ts"][i] for i in range(B)), tuple(bufs["x_static"][i] for i in range(B)),
-                            tuple(bufs["bin_ends"][i] for i in range(B)), bufs["pixel_values"])["main_logit"]
+                            tuple(bufs["bin_ends"][i] for i in range(B)), bufs["pixel_values"], **kw)["main_logit"]
 
     def _frozen_forward(self):
+        # this forward IS a forked branch of the capture: it must not fork again (nested forks crash hipStreamEndCapture here)
         with torch.no_grad():
-            self.z_next = self._teacher_logit(self.nxt)
+            self.z_next = self._teacher_logit(self.nxt, forked=True)
 
     def _stateful_modules(self):
         return [self.student, self.teacher]

@@ -228,16 +228,16 @@ class DualPathologyPerceiver(nn.Module):
 
     def _grouped_heads(self, T_kbd, heads, seed, sid):
         """T_kbd [K, B, d] -> [B, K]: head k on rows of pathology k."""
-        from .duett_train import AxisSwapFn, GLinearFn
+        from .duett_train import GLinearFn
         K, B, _ = T_kbd.shape
         p = float(heads[0][2].p) if heads[0][2].training else 0.0
         h = GLinearFn.apply(T_kbd, torch.stack([m[0].weight for m in heads]), torch.stack([m[0].bias for m in heads]))
         h = A.gelu_dropout(h, p, seed, sid)
         z = GLinearFn.apply(h, torch.stack([m[3].weight for m in heads]), torch.stack([m[3].bias for m in heads]))     # [K, B, 1]
-        return AxisSwapFn.apply(z.view(1, K, B, 1)).view(B, K)
+        return z.view(K, B).t().contiguous()                     # [B, K] (7 x B scalars: layout plumbing)
 
     def forward(self, ts_tokens, img_logits, return_attn: bool = False, ts_ablation: str = "hourly_only") -> dict:
-        from .duett_train import AddBcastFn, AxisSwapFn
+        from .duett_train import AxisSwapFn
         ts_selected = PatchDualPathologyPerceiver._select_ts(self, ts_tokens, ts_ablation)
         B = ts_tokens.size(0)
         seed = A.next_seed() if self.training else 0
@@ -250,7 +250,7 @@ class DualPathologyPerceiver(nn.Module):
         T_kbd = AxisSwapFn.apply(T_tok.reshape(1, B, K, d)).view(K, B, d)
         ts_logits = self._grouped_heads(T_kbd, self.temporal_heads, seed, _SID["temporal_head"])
         residuals = self._grouped_heads(T_kbd, self.residual_heads, seed, _SID["residual_head"])
-        fusion_logits = AddBcastFn.apply(residuals, img_logits.detach().view(B, K, 1).reshape(B, K))   # img_logits: passthrough, no gradient
+        fusion_logits = A.dropout_add(residuals, img_logits.detach(), 0.0, 0, 0)          # plain add; img_logits: passthrough, no gradient
         out = {"img_logits": img_logits, "ts_logits": ts_logits, "fusion_logits": fusion_logits, "ts_tokens": T_tok,
                "residuals": residuals}
         if return_attn:
@@ -334,9 +334,12 @@ class TeacherModel(nn.Module):
         return result
 
     def forward(self, x_ts_list, x_static_list, bin_ends_list, pixel_values: torch.Tensor, batch_size: Optional[int] = None,
-                return_attn: bool = False, *, _cxr_tokens16: Optional[torch.Tensor] = None):
+                return_attn: bool = False, *, _cxr_tokens16: Optional[torch.Tensor] = None, _overlap: Optional[bool] = None):
         """`_cxr_tokens16` (bf16 [B, P+1, d_img], private): tokens of the FROZEN CXR encoder for `pixel_values`, computed
-        ahead of time — graph_step.py runs the encoder for the next batch beside this batch's training step."""
+        ahead of time — graph_step.py runs the encoder for the next batch beside this batch's training step.
+        `_overlap=False` (private): keep the whole forward on the current stream — needed when this forward is itself a forked
+        branch of a graph capture (the frozen KD teacher beside the student's step): a fork nested inside a forked stream makes
+        hipStreamEndCapture crash on this ROCm (segmentation fault in capture_end)."""
         if batch_size is None:
             batch_size = pixel_values.shape[0]
         x = (x_ts_list, x_static_list, bin_ends_list)
@@ -355,7 +358,7 @@ class TeacherModel(nn.Module):
         # GEMMs they fill otherwise idle issue slots.  autograd replays each node's backward on its forward stream, so the
         # two halves of the backward overlap the same way.  MEDP_OVERLAP=0 runs everything on one stream.
         cur = torch.cuda.current_stream()
-        side = _side_stream(pixel_values.device) if _OVERLAP else None
+        side = _side_stream(pixel_values.device) if (_OVERLAP and _overlap is not False) else None
         if side is not None:
             side.wait_stream(cur)
             for t in (q0,) + tuple(duett_in):

@@ -150,6 +150,17 @@ class FusedAdamW(torch.optim.Optimizer):
             self._table[i].lr = lr_of[id(p)]
         self._upload_table()
 
+    def relaunch(self) -> None:
+        """Issue the optimiser's two launches again over the table as it stands on the device (same tensors, same gradient
+        buffers — the flat-arena step of graph_step.py, where `refresh_lrs()` has just uploaded this step's rates): the whole
+        update without rebuilding the table on the host and without a second graph."""
+        betas, eps = self.param_groups[0]["betas"], self.param_groups[0]["eps"]
+        self._step += 1
+        check(lib().medp_counter_advance(ptr(self.dev_step), stream()), "counter_advance")
+        check(lib().medp_adamw_multi(ptr(self._descs_dev), ptr(self._blk_t), ptr(self._blk_c), self._blk_t.numel(), betas[0], betas[1],
+                                     eps, self._step, ptr(self.dev_step), 1.0, stream()), "adamw_multi")
+        torch.autograd.graph.increment_version([p for p, *_ in self._entries])
+
     def current_lrs(self) -> list:
         """Per-tensor learning rates of the table as last built (tests)."""
         return [float(self._table[i].lr) for i in range(len(self._entries))]

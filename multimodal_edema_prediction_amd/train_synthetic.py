@@ -200,8 +200,10 @@ def train_teacher(args) -> dict:
             break
     if world > 1:
         torch.distributed.barrier()
-    state = checkpoint.load_ckpt(best_path)                      # reload best (the reference does it on rank 0 only, :719-721)
-    checkpoint.load_model_state(teacher, state)
+    state = {"epoch": None}
+    if os.path.exists(best_path):                                # reload best (the reference does it on rank 0 only, :719-721)
+        state = checkpoint.load_ckpt(best_path)
+        checkpoint.load_model_state(teacher, state)
     test = evaluator.evaluate_dual_pathology(teacher, make_loader(test_ds, args.batch_size, False, args.num_workers, "teacher", rank, world),
                                              device, labels, gather=True)
     _log(rank, f"[teacher] test macro-AUROC {test['main_auroc']:.4f} macro-AUPRC {test['main_auprc']:.4f} (best epoch {state['epoch']})")
@@ -287,7 +289,8 @@ def train_student(args) -> dict:
             break
     if world > 1:
         torch.distributed.barrier()
-    checkpoint.load_model_state(student, checkpoint.load_ckpt(best_path))
+    if os.path.exists(best_path):          # a validation AUROC that is never defined (one class only) saves nothing, as in the reference
+        checkpoint.load_model_state(student, checkpoint.load_ckpt(best_path))
     test = evaluator.evaluate_binary(student, make_loader(test_ds, args.batch_size, False, args.num_workers, "teacher", rank, world), device,
                                      fwd, gather=True)
     _log(rank, f"[student] test AUROC {test['auroc']:.4f} AUPRC {test['auprc']:.4f}")
