@@ -172,7 +172,7 @@ def cpu_baseline(config, model, teacher, ccfg, K, batch_cpu, target_seconds=15.0
     t0 = time.perf_counter()
     run()                                                            # warm-up (thread pools, allocator)
     warm = time.perf_counter() - t0
-    steps = max(1, min(8, int((target_seconds - warm) / max(warm, 1e-3))))
+    steps = max(1, min(64, int((target_seconds - warm) / max(warm, 1e-3))))      # ~15 s of CPU work
     t0 = time.perf_counter()
     for _ in range(steps):
         run()
@@ -182,7 +182,7 @@ def cpu_baseline(config, model, teacher, ccfg, K, batch_cpu, target_seconds=15.0
                       f"through the fp32 CPU oracle, torch.set_num_threads({cores}), {dt:.1f} s"}
 
 
-def hbm_kernel_table(B, T, V, device):
+def hbm_kernel_table(B, T, V, device, duett=None):
     """The HBM-bound kernels SURVEY.md §8(d) asks to be reported one by one: algorithmic bytes (each operand read once, each result
     written once), live HIP-event time of isolated launches at the step's shapes, fraction of 8 TB/s."""
     import torch
@@ -216,6 +216,25 @@ def hbm_kernel_table(B, T, V, device):
     w, b = torch.ones(768, device=device), torch.zeros(768, device=device)
     us = timeit(lambda: Fn.layernorm(x, w, b, 1e-6))
     rows.append(("layernorm_fwd_reg_kernel (ViT tokens, fp32 -> bf16)", x.numel() * 6, us))
+    if duett is not None:                      # the fused DuETT front end (csrc/duett.hip), at the step's shapes
+        psi_elems = B * T1 * V1 * E
+        xs_static, xs_ts, xs_times = torch.randn(B, 8, device=device), torch.zeros(B, T, 2 * V + 1, device=device), torch.rand(B, T, device=device)
+        xs_ts[:, :, :V] = torch.randn(B, T, V, device=device)
+        xs_ts[:, :, V:2 * V] = torch.randint(0, 4, (B, T, V), device=device).float()
+        w = duett._prepare()[0]
+        xe, h = torch.empty(psi_elems, device=device), torch.empty(psi_elems, device=device, dtype=torch.bfloat16)
+        temb, tab = torch.empty(psi_elems, device=device), torch.empty(B * E, device=device)
+        emb = lambda st: check(lib().medp_duett_embed_fwd(ctypes.byref(w), ptr(xs_static), ptr(xs_ts), ptr(xs_times), B, T, ptr(xe), ptr(h),
+                                                          ptr(temb), None, ptr(tab), st, stream()), "duett_embed_fwd")
+        us = timeit(lambda: emb(1))
+        rows.append(("tab_encoder + psi_embed_event_kernel (psi build + swap + event embedding + ScaleNorm -> fp32 + bf16)",
+                     xs_ts.numel() * 4 + V1 * T1 * E * 4 + psi_elems * 6, us))
+        us = timeit(lambda: emb(2))
+        rows.append(("time_embed_kernel (cve 1 -> 34 -> 1176, REP row appended, fp32)", xs_times.numel() * 4 + psi_elems * 4, us))
+        g1, rn = torch.ones(1, device=device), torch.rand(B * V1, device=device)
+        us = timeit(lambda: check(lib().medp_duett_swap_add_norm(ptr(xe), ptr(rn), ptr(g1), ptr(temb), T1 * V1 * E, ptr(g1), 1e-12, ptr(psi), ptr(h),
+                                                                 B, V1, T1, E, stream()), "swap_add_norm"))
+        rows.append(("swap_add_norm_kernel (event -> time view + time embedding + ScaleNorm -> fp32 + bf16)", psi_elems * (4 + 4 + 4 + 2), us))
     return [{"kernel": n, "algorithmic_bytes": int(by), "us": round(us, 2), "GBps": round(by / us * 1e-3, 1),
              "frac_of_hbm_peak": round(by / us * 1e-3 / PEAK_HBM_GBS, 4)} for n, by, us in rows]
 
@@ -498,7 +517,7 @@ def main():
             "note": "the matrix peak is the nominal roofline; L2 counters (profiles/r01_pmc_tcc_gemm_v6_v7.txt) show the L2 channels 79 % busy "
                     "at 8.1 TB/s of LDS staging traffic: at 128 FLOP per staged byte the binding ceiling is ~1.05 PFLOP/s"}
         if world == 1 and not args.no_hbm_table and not args.stress:
-            res["roofline"]["hbm_kernels"] = hbm_kernel_table(B, T, V, device)
+            res["roofline"]["hbm_kernels"] = hbm_kernel_table(B, T, V, device, teacher.duett)
     if world == 1 and not args.no_cpu_baseline and not args.stress and not args.unfreeze_cxr:
         cb = make_batch(ccfg, start=10_000, batch_size=4, mode="teacher")
         res["cpu_baseline"] = cpu_baseline(cfg, trainable, teacher, ccfg, K, cb)

@@ -41,6 +41,15 @@ int medp_gemm_bf16_nt(const void* A, const void* W, void* C, int M, int N, int K
                       const float* bias, const float* scale, const float* residual, int ldr, int act, int out_bf16,
                       void* stream);
 
+/* The same GEMM with a caller-owned workspace: small grids (DuETT's skinny GEMMs, duett/duett.py:95-105 at M = B(V+1) / B(T+1) rows:
+ * 25-100 tiles for 256 CUs) are split along K into slices that fill the chip; the slices' fp32 partial sums go to the workspace
+ * and a second pass sums them in a fixed order and applies the epilogue (deterministic, no atomics).
+ * medp_gemm_nt_workspace_bytes returns 0 where the one-pass kernel is used anyway. */
+size_t medp_gemm_nt_workspace_bytes(int M, int N, int K);
+int medp_gemm_bf16_nt_ws(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldw, int ldc, const float* bias,
+                         const float* scale, const float* residual, int ldr, int act, int out_bf16, float* workspace,
+                         size_t workspace_bytes, void* stream);
+
 /* Weight gradient C[N,K] = sum_m dY[m,n] X[m,k] (fp32 out, bf16 row-major operands, transposing LDS reads, split over m with
  * a deterministic slab reduction): the dW of every trainable Linear (autograd of model :566,:749-757,:1027, duett.py:95-105). */
 size_t medp_gemm_tn_workspace_bytes(int M, int N, int K);
@@ -179,6 +188,21 @@ typedef struct {
     const MedpEncoderWeights* event_enc;   /* HOST arrays of n_layers entries */
     const MedpEncoderWeights* time_enc;
 } MedpDuettWeights;
+
+/* The embedding stage of medp_duett_encode on its own (model :41-69; kernel-level parity and the per-kernel HBM table of bench.py).
+ * stages bit 0: static encoder + FUSED psi build: psi (model :45-66) is produced directly in the EVENT view with the event
+ *   embedding added (model :80) and the event encoder's first ScaleNorm applied: xe_out fp32 [B, V+1, (T+1)E], h_out bf16 (same
+ *   shape), psi0_out (optional) psi in the time view [B, T+1, V+1, E] before the add; tab_workspace: B*E floats.
+ * stages bit 1: time embedding cve(xs_times) with the REP row appended (model :67-69): temb_out fp32 [B, T+1, (V+1)E]. */
+int medp_duett_embed_fwd(const MedpDuettWeights* host_w, const float* xs_static, const float* xs_ts, const float* xs_times, int B, int T,
+                         float* xe_out, void* h_out_bf16, float* temb_out, float* psi0_out, float* tab_workspace, int stages, void* stream);
+/* Axis swap + positional add + the next encoder's first ScaleNorm in one pass (model :80 / :90 + x_transformers pre-norm):
+ * x_out[b][a2][a1][:] = in[b][a1][a2][:] * rowscale(b,a1) + add, h_out = ScaleNorm(x_out) as bf16.  rowscale applies the previous
+ * encoder's pending final ScaleNorm (rnorm [B*A1] from medp_scalenorm_fwd, gain g_prev) or is 1 when rnorm is NULL.
+ * add: [A2, A1, E] (add_batch_stride 0) or [B, A2, A1, E] (stride A2*A1*E). */
+int medp_duett_swap_add_norm(const float* in, const float* rnorm, const float* g_prev, const float* add, long long add_batch_stride,
+                             const float* g_norm, float norm_eps, float* x_out, void* h_out_bf16, int B, int A1, int A2, int E,
+                             void* stream);
 
 /* ---- device-side batch assembly -------------------------------------------------------------------------
  * medp_feats_to_input replaces the host loop of Model.feats_to_input (duett/duett.py:159-187): sample b is a ragged series

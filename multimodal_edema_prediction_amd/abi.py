@@ -55,6 +55,8 @@ SIGNATURES = {
     "medp_version": (I, []),
     "medp_arch": (c_char_p, []),
     "medp_gemm_bf16_nt": (I, [P, P, P, I, I, I, I, I, I, P, P, P, I, I, I, P]),
+    "medp_gemm_nt_workspace_bytes": (SZ, [I, I, I]),
+    "medp_gemm_bf16_nt_ws": (I, [P, P, P, I, I, I, I, I, I, P, P, P, I, I, I, P, SZ, P]),
     "medp_gemm_tn_workspace_bytes": (SZ, [I, I, I]),
     "medp_gemm_bf16_tn": (I, [P, P, P, I, I, I, I, I, P, P]),
     "medp_gemm_profile_enable": (I, [I]),
@@ -83,6 +85,8 @@ SIGNATURES = {
     "medp_vit_workspace_bytes": (SZ, [ctypes.POINTER(MedpVitWeights), I, I, I]),
     "medp_vit_forward": (I, [ctypes.POINTER(MedpVitWeights), P, I, I, I, P, P, P, SZ, P]),
     "medp_vit_forward_part": (I, [ctypes.POINTER(MedpVitWeights), P, I, I, I, P, P, P, SZ, I, I, P]),
+    "medp_duett_embed_fwd": (I, [ctypes.POINTER(MedpDuettWeights), P, P, P, I, I, P, P, P, P, P, I, P]),
+    "medp_duett_swap_add_norm": (I, [P, P, P, P, LL, P, F, P, P, I, I, I, I, P]),
     "medp_feats_to_input": (I, [P, P, LL, P, P, LL, P, I, P, P, P, P, I, I, I, I, I, F, F, U, U, P]),
     "medp_ssl_mask_batch": (I, [P, P, P, P, P, P, P, P, P, I, I, I, P]),
     "medp_duett_workspace_bytes": (SZ, [ctypes.POINTER(MedpDuettWeights), I, I]),

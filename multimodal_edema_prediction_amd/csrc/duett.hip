@@ -188,8 +188,177 @@ __global__ __launch_bounds__(256) void axis_swap_add_kernel(const float* __restr
     }
 }
 
+// ---- layer-0 fusion: psi build + (time view -> event view) + event embedding + the event encoder's first ScaleNorm -----------
+// One workgroup per event-view row (b, v): its T+1 cells are CONTIGUOUS in the event view ((T+1)*E floats), so the row is
+// assembled in LDS and leaves in whole-row coalesced 16-B stores — the time-view psi kernel above writes 96-B cells 4.7 KB apart.
+// It replaces psi_embed + axis_swap_add + scalenorm of layer 0 (psi0 is never written; reads 2.4 MB, writes |psi| fp32 + bf16).
+// The row's sum of squares is taken by wave 0 in the lane / chunk order of scalenorm_fwd_reg_kernel, so `h` is bit-identical to
+// what the separate ScaleNorm launch produced.
+template <int E, int HD>
+__global__ __launch_bounds__(128) void psi_embed_event_kernel(const float* __restrict__ xs_ts, const float* __restrict__ w0,
+                                                              const float* __restrict__ b0, const float* __restrict__ bs,
+                                                              const float* __restrict__ bsh, const float* __restrict__ w4,
+                                                              const float* __restrict__ b4, const float* __restrict__ nobs_table,
+                                                              int nobs_rows, const float* __restrict__ tab_out,
+                                                              const float* __restrict__ special, const float* __restrict__ event_emb,
+                                                              const float* __restrict__ g_norm, float norm_eps, float* __restrict__ xe,
+                                                              bf16_t* __restrict__ h, float* __restrict__ psi0_out, int B, int T, int V) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];          // [(T+1)*E] the row, then weights
+    __shared__ __attribute__((aligned(16))) float sw0[HD * 2], sb0[HD], ss_[HD], ssh[HD], sw4t[HD * E], sb4[E];   // sw4t = second Linear TRANSPOSED [HD][E]
+    __shared__ float s_rn;
+    const int v = blockIdx.x, b = blockIdx.y;
+    const int T1 = T + 1, F = 2 * V + 1, D = T1 * E, D4 = D >> 2;
+    if (v < V) {
+        for (int i = threadIdx.x; i < HD * 2; i += 128) sw0[i] = w0[(size_t)v * HD * 2 + i];
+        for (int i = threadIdx.x; i < HD; i += 128) {
+            sb0[i] = b0[(size_t)v * HD + i];
+            ss_[i] = bs[(size_t)v * HD + i];
+            ssh[i] = bsh[(size_t)v * HD + i];
+        }
+        for (int i = threadIdx.x; i < E * HD; i += 128) sw4t[(i % HD) * E + i / HD] = w4[(size_t)v * E * HD + i];   // [e][j] -> [j][e]
+        for (int i = threadIdx.x; i < E; i += 128) sb4[i] = b4[(size_t)v * E + i];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < T1; t += 128) {
+        float out[E];
+        const float* src = nullptr;
+        if (t == T) {
+            src = special + E;                                   // REP row                                 (model :58-60)
+        } else {
+            const float* row = xs_ts + ((size_t)b * T + t) * F;
+            if (row[2 * V] == 1.0f) {
+                src = special;                                   // masked timestep                         (model :61-64)
+            } else if (v == V) {
+                src = tab_out + (size_t)b * E;                   // static column                           (model :57)
+            } else {
+                const float cnt = row[V + v];
+                if (cnt == -1.0f) {
+                    src = special;                               // masked event (SSL only)                 (model :65-66)
+                } else {
+                    const int idx = min(max((int)cnt, 0), nobs_rows - 1);
+                    const float val = row[v], nob = nobs_table[idx];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) out[e] = sb4[e];
+#pragma unroll 8
+                    for (int j = 0; j < HD; ++j) {
+                        const float hj = fmaxf(sw0[2 * j] * val + sw0[2 * j + 1] * nob + sb0[j], 0.f) * ss_[j] + ssh[j];
+                        const float4* wj = (const float4*)(sw4t + j * E);       // one broadcast 16-B read per 4 outputs, packed FMAs
+#pragma unroll
+                        for (int e4 = 0; e4 < E / 4; ++e4) {
+                            const float4 w = wj[e4];
+                            out[4 * e4] += w.x * hj; out[4 * e4 + 1] += w.y * hj; out[4 * e4 + 2] += w.z * hj; out[4 * e4 + 3] += w.w * hj;
+                        }
+                    }
+                }
+            }
+        }
+        if (src) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) out[e] = src[e];
+        }
+        if (psi0_out) {                                          // parity checks only: psi0 in the time view, before the add
+            float* d0 = psi0_out + (((size_t)b * T1 + t) * (V + 1) + v) * E;
+#pragma unroll
+            for (int e = 0; e < E; e += 4) *(float4*)(d0 + e) = make_float4(out[e], out[e + 1], out[e + 2], out[e + 3]);
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) tile[t * E + e] = out[e];
+    }
+    __syncthreads();
+    // + event embedding (row v of [V+1, (T+1)E]) ; fp32 row out, coalesced
+    const size_t rbase = ((size_t)b * (V + 1) + v) * D;
+    for (int i = threadIdx.x; i < D4; i += 128) {
+        float4 x = *(float4*)(tile + 4 * i);
+        const float4 a = *(const float4*)(event_emb + (size_t)v * D + 4 * i);
+        x = make_float4(x.x + a.x, x.y + a.y, x.z + a.z, x.w + a.w);
+        *(float4*)(tile + 4 * i) = x;
+        *(float4*)(xe + rbase + 4 * i) = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {                                      // canonical order: lane + 64 k, then the wave tree
+        float ss = 0.f;
+        for (int i = threadIdx.x; i < D4; i += 64) {
+            const float4 x = *(const float4*)(tile + 4 * i);
+            ss += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+        }
+        const float rn = 1.0f / fmaxf(sqrtf(wave_sum(ss)), norm_eps);
+        if (threadIdx.x == 0) s_rn = rn;
+    }
+    __syncthreads();
+    const float sc = s_rn * sqrtf((float)D) * g_norm[0];
+    for (int i = threadIdx.x; i < D4; i += 128) {
+        const float4 x = *(const float4*)(tile + 4 * i);
+        uint2 o;
+        o.x = pack_bf2(x.x * sc, x.y * sc);
+        o.y = pack_bf2(x.z * sc, x.w * sc);
+        *(uint2*)(h + rbase + 4 * i) = o;
+    }
+}
+
+// ---- axis swap + positional add + the NEXT encoder's first ScaleNorm in one pass (wave per output row, row in registers) --------
+// x[b][a2][a1][:] = in[b][a1][a2][:] * rowscale(b, a1) + add ;  h = ScaleNorm(x) as bf16.  One read of psi, one fp32 + one bf16
+// write, instead of swap (read + write) then ScaleNorm (read + write).  Lane / chunk order of scalenorm_fwd_reg_kernel: bit-identical.
+template <int NV>
+__global__ __launch_bounds__(256) void swap_add_norm_kernel(const float* __restrict__ in, const float* __restrict__ rnorm,
+                                                            const float* __restrict__ g_prev, float gain_sqrt_dim,
+                                                            const float* __restrict__ add, long long add_bs,
+                                                            const float* __restrict__ g_norm, float norm_eps, float* __restrict__ x_out,
+                                                            bf16_t* __restrict__ h_out, int B, int A1, int A2, int E4) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * A2) return;
+    const int b = row / A2, a2 = row - b * A2;
+    const int D4 = A1 * E4, D = D4 * 4;
+    const float gain = rnorm ? gain_sqrt_dim * g_prev[0] : 1.f;
+    const float* addr = add + (size_t)b * add_bs + (size_t)a2 * D;
+    float4 v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = lane + 64 * k;
+        v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < D4) {
+            const int a1 = i / E4, e4 = i - a1 * E4;
+            const float4 s = *(const float4*)(in + ((((size_t)b * A1 + a1) * A2 + a2) * E4 + e4) * 4);
+            const float sc = rnorm ? rnorm[(size_t)b * A1 + a1] * gain : 1.f;
+            const float4 ad = *(const float4*)(addr + 4 * i);
+            v[k] = make_float4(s.x * sc + ad.x, s.y * sc + ad.y, s.z * sc + ad.z, s.w * sc + ad.w);
+            *(float4*)(x_out + (size_t)row * D + 4 * i) = v[k];
+        }
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+        if (lane + 64 * k < D4) ss += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
+    const float rn = 1.0f / fmaxf(sqrtf(wave_sum(ss)), norm_eps);
+    const float sc = rn * sqrtf((float)D) * g_norm[0];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = lane + 64 * k;
+        if (i < D4) {
+            uint2 o;
+            o.x = pack_bf2(v[k].x * sc, v[k].y * sc);
+            o.y = pack_bf2(v[k].z * sc, v[k].w * sc);
+            *(uint2*)(h_out + (size_t)row * D + 4 * i) = o;
+        }
+    }
+}
+
+int launch_swap_add_norm(const float* in, const float* rnorm, const float* g_prev, float gain_sqrt_dim, const float* add, long long add_bs,
+                         const float* g_norm, float norm_eps, float* x_out, void* h_out, int B, int A1, int A2, int E4, hipStream_t s) {
+    const int nv = (A1 * E4 + 63) / 64, grid = (B * A2 + 3) / 4;
+#define MEDP_SAN(NV) swap_add_norm_kernel<NV><<<grid, 256, 0, s>>>(in, rnorm, g_prev, gain_sqrt_dim, add, add_bs, g_norm, norm_eps, x_out, (bf16_t*)h_out, B, A1, A2, E4)
+    if (nv <= 5) MEDP_SAN(5);
+    else if (nv <= 10) MEDP_SAN(10);
+    else if (nv <= 16) MEDP_SAN(16);
+    else if (nv <= 25) MEDP_SAN(25);
+    else return 1;          // wider rows: the caller takes the two-launch path
+#undef MEDP_SAN
+    MEDP_LAUNCH_CHECK("duett swap+add+norm");
+    return 0;
+}
+
 struct DuettWs {
-    size_t tab, psi, xe, xt, temb, h, qkv, o, f, rn, total;
+    size_t tab, psi, xe, xt, temb, h, qkv, o, f, rn, split, split_bytes, total;
 };
 DuettWs plan(const MedpDuettWeights* w, int B, int T) {
     const size_t V1 = w->n_vars + 1, T1 = T + 1, E = w->d_embedding;
@@ -207,26 +376,38 @@ DuettWs plan(const MedpDuettWeights* w, int B, int T) {
     s.o = off;    off += al(rows * E * 2);
     s.f = off;    off += al(rows * (size_t)w->d_ff * 2);
     s.rn = off;   off += al(rows * 4);
+    // split-K partial sums of the skinny GEMMs (medp_gemm_bf16_nt_ws): the largest need over both axes' four shapes
+    size_t sp = 0;
+    for (int axis = 0; axis < 2; ++axis) {
+        const int M = (int)(B * (axis ? T1 : V1)), D = (int)(E * (axis ? V1 : T1));
+        sp = max(sp, medp_gemm_nt_workspace_bytes(M, 3 * (int)E, D));
+        sp = max(sp, medp_gemm_nt_workspace_bytes(M, D, (int)E));
+        sp = max(sp, medp_gemm_nt_workspace_bytes(M, w->d_ff, D));
+        sp = max(sp, medp_gemm_nt_workspace_bytes(M, D, w->d_ff));
+    }
+    s.split = off; s.split_bytes = sp; off += al(sp);
     s.total = off;
     return s;
 }
 
 // one x_transformers encoder block on x [M = B*N tokens, D] (in place); leaves the FINAL ScaleNorm to the caller
 int encoder_forward(const MedpEncoderWeights& e, const MedpDuettWeights* w, float* x, int B, int N, int D, char* base,
-                    const DuettWs& ws, void* stream) {
+                    const DuettWs& ws, void* stream, bool h_ready = false) {
     const int M = B * N, E = w->d_embedding, H = w->n_heads, dh = E / H;
     void* h = base + ws.h;
     float* qkv = (float*)(base + ws.qkv);
     void* o = base + ws.o;
     void* f = base + ws.f;
-    MEDP_TRY(medp_scalenorm_fwd(x, D, e.g_attn, h, D, 1, nullptr, M, D, w->norm_eps, stream));
-    MEDP_TRY(medp_gemm_bf16_nt(h, e.qkv_w, qkv, M, 3 * E, D, D, D, 3 * E, nullptr, nullptr, nullptr, 0, 0, 0, stream));
+    float* sp = (float*)(base + ws.split);
+    if (!h_ready)      // else: the producer of x (embed / swap kernel) has written ScaleNorm(x) to ws.h already
+        MEDP_TRY(medp_scalenorm_fwd(x, D, e.g_attn, h, D, 1, nullptr, M, D, w->norm_eps, stream));
+    MEDP_TRY(medp_gemm_bf16_nt_ws(h, e.qkv_w, qkv, M, 3 * E, D, D, D, 3 * E, nullptr, nullptr, nullptr, 0, 0, 0, sp, ws.split_bytes, stream));
     MEDP_TRY(medp_attn_small_fwd(qkv, 3 * E, (long long)N * 3 * E, qkv + E, qkv + 2 * E, 3 * E, (long long)N * 3 * E, o, E, 1, nullptr,
                                  B, N, N, H, dh, 1.0f / sqrtf((float)dh), 0.f, 0u, 0u, stream));
-    MEDP_TRY(medp_gemm_bf16_nt(o, e.out_w, x, M, D, E, E, E, D, nullptr, nullptr, x, D, 0, 0, stream));
+    MEDP_TRY(medp_gemm_bf16_nt_ws(o, e.out_w, x, M, D, E, E, E, D, nullptr, nullptr, x, D, 0, 0, sp, ws.split_bytes, stream));
     MEDP_TRY(medp_scalenorm_fwd(x, D, e.g_ff, h, D, 1, nullptr, M, D, w->norm_eps, stream));
-    MEDP_TRY(medp_gemm_bf16_nt(h, e.ff1_w, f, M, w->d_ff, D, D, D, w->d_ff, e.ff1_b, nullptr, nullptr, 0, 1, 1, stream));
-    MEDP_TRY(medp_gemm_bf16_nt(f, e.ff2_w, x, M, D, w->d_ff, w->d_ff, w->d_ff, D, e.ff2_b, nullptr, x, D, 0, 0, stream));
+    MEDP_TRY(medp_gemm_bf16_nt_ws(h, e.ff1_w, f, M, w->d_ff, D, D, D, w->d_ff, e.ff1_b, nullptr, nullptr, 0, 1, 1, sp, ws.split_bytes, stream));
+    MEDP_TRY(medp_gemm_bf16_nt_ws(f, e.ff2_w, x, M, D, w->d_ff, w->d_ff, w->d_ff, D, e.ff2_b, nullptr, x, D, 0, 0, sp, ws.split_bytes, stream));
     return 0;
 }
 
@@ -263,43 +444,68 @@ extern "C" int medp_duett_encode(const MedpDuettWeights* w, const float* xs_stat
                                                                        (const float*)w->tab_w4, (const float*)w->tab_b4, tab,
                                                                        w->n_static, w->d_hidden_tab, E);
     MEDP_LAUNCH_CHECK("duett tab_encoder");
-    psi_embed_kernel<24, 64><<<dim3((B * T1 + 255) / 256, V1), 256, 0, s>>>(
-        xs_ts, (const float*)w->emb_w0, (const float*)w->emb_b0, (const float*)w->emb_bn_scale, (const float*)w->emb_bn_shift,
-        (const float*)w->emb_w4, (const float*)w->emb_b4, (const float*)w->n_obs_table, w->n_obs_rows, tab, (const float*)w->special, psi,
-        B, T, V);
-    MEDP_LAUNCH_CHECK("duett psi_embed");
-    if (psi0_out) {
-        hipError_t e = hipMemcpyAsync(psi0_out, psi, (size_t)B * T1 * V1 * E * 4, hipMemcpyDeviceToDevice, s);
-        MEDP_CHECK_ARG(e == hipSuccess, "duett_encode: psi0 copy failed");
+    const int E4 = E / 4;
+    MEDP_CHECK_ARG((size_t)B * T1 * V1 * E4 < (1ull << 31), "duett_encode: B*(T+1)*(V+1)*E/4 must stay below 2^31");
+    MEDP_CHECK_ARG((size_t)T1 * E * 4 <= 100 * 1024, "duett_encode: a (T+1)*E row must fit the embed kernel's LDS tile");
+    // Layer 0, event view, in ONE launch: psi build + axis swap + event embedding + the event encoder's first ScaleNorm.
+    // MEDP_DUETT_FUSED=0 keeps the separate launches (psi_embed -> swap -> scalenorm ...) for A/B runs; same values.
+    static const bool fused = [] { const char* e = getenv("MEDP_DUETT_FUSED"); return !e || atoi(e) != 0; }();
+    const int swap_grid = grid_for((size_t)B * T1 * V1 * E4);
+    if (fused) {
+        psi_embed_event_kernel<24, 64><<<dim3(V1, B), 128, (size_t)T1 * E * sizeof(float), s>>>(
+            xs_ts, (const float*)w->emb_w0, (const float*)w->emb_b0, (const float*)w->emb_bn_scale, (const float*)w->emb_bn_shift,
+            (const float*)w->emb_w4, (const float*)w->emb_b4, (const float*)w->n_obs_table, w->n_obs_rows, tab, (const float*)w->special,
+            (const float*)w->event_embedding, (const float*)w->event_enc[0].g_attn, w->norm_eps, xe, (bf16_t*)(base + ws.h), psi0_out, B, T, V);
+        MEDP_LAUNCH_CHECK("duett psi_embed_event");
+    } else {
+        psi_embed_kernel<24, 64><<<dim3((B * T1 + 255) / 256, V1), 256, 0, s>>>(
+            xs_ts, (const float*)w->emb_w0, (const float*)w->emb_b0, (const float*)w->emb_bn_scale, (const float*)w->emb_bn_shift,
+            (const float*)w->emb_w4, (const float*)w->emb_b4, (const float*)w->n_obs_table, w->n_obs_rows, tab, (const float*)w->special, psi,
+            B, T, V);
+        MEDP_LAUNCH_CHECK("duett psi_embed");
+        if (psi0_out) {
+            hipError_t e = hipMemcpyAsync(psi0_out, psi, (size_t)B * T1 * V1 * E * 4, hipMemcpyDeviceToDevice, s);
+            MEDP_CHECK_ARG(e == hipSuccess, "duett_encode: psi0 copy failed");
+        }
     }
     time_embed_kernel<<<dim3((B * T1 + TE_ROWS - 1) / TE_ROWS, (tt + 255) / 256), 256, TE_ROWS * w->d_hidden_time * sizeof(float), s>>>(
         xs_times, (const float*)w->time_w0, (const float*)w->time_b0, (const float*)w->time_bn_scale, (const float*)w->time_bn_shift,
         (const float*)w->time_w3t, (const float*)w->time_b3, (const float*)w->rep_embedding, temb, B, T, w->d_hidden_time, tt);
     MEDP_LAUNCH_CHECK("duett time_embed");
 
-    const int E4 = E / 4;
-    MEDP_CHECK_ARG((size_t)B * T1 * V1 * E4 < (1ull << 31), "duett_encode: B*(T+1)*(V+1)*E/4 must stay below 2^31");
-    const int swap_grid = grid_for((size_t)B * T1 * V1 * E4);
     const float* cur = psi;          // time view [B, T1, V1, E]; rows (b,t) of tt features
     const float* cur_rn = nullptr;   // pending final-ScaleNorm row scales of `cur`
     const float* cur_g = nullptr;
     for (int l = 0; l < w->n_layers; ++l) {
         // time view -> event view (+ event embedding), applying the previous time encoder's final norm      (model :80)
-        axis_swap_add_kernel<<<swap_grid, 256, 0, s>>>(cur, cur_rn, cur_g, sqrtf((float)tt), (const float*)w->event_embedding, 0, xe, B, T1,
-                                                       V1, E4);
-        MEDP_LAUNCH_CHECK("duett swap t->e");
-        MEDP_TRY(encoder_forward(w->event_enc[l], w, xe, B, V1, et, base, ws, stream));                      // (model :81)
+        bool h_ready = fused && l == 0;          // layer 0: the embed kernel wrote xe and ScaleNorm(xe) already
+        if (!h_ready) {
+            if (fused && launch_swap_add_norm(cur, cur_rn, cur_g, sqrtf((float)tt), (const float*)w->event_embedding, 0,
+                                              (const float*)w->event_enc[l].g_attn, w->norm_eps, xe, base + ws.h, B, T1, V1, E4, s) == 0) {
+                h_ready = true;
+            } else {
+                axis_swap_add_kernel<<<swap_grid, 256, 0, s>>>(cur, cur_rn, cur_g, sqrtf((float)tt), (const float*)w->event_embedding, 0, xe, B,
+                                                               T1, V1, E4);
+                MEDP_LAUNCH_CHECK("duett swap t->e");
+            }
+        }
+        MEDP_TRY(encoder_forward(w->event_enc[l], w, xe, B, V1, et, base, ws, stream, h_ready));              // (model :81)
         const float* e_rn = nullptr;
         if (w->final_norm) {
             // final ScaleNorm of the event encoder: statistics now, scaling fused into the swap below
             MEDP_TRY(medp_scalenorm_fwd(xe, et, w->event_enc[l].g_final, base + ws.h, et, 1, rn, B * V1, et, w->norm_eps, stream));
             e_rn = rn;
         }
-        // event view -> time view (+ time embedding)                                                          (model :81,:90)
-        axis_swap_add_kernel<<<swap_grid, 256, 0, s>>>(xe, e_rn, (const float*)w->event_enc[l].g_final, sqrtf((float)et), temb,
-                                                       (long long)T1 * V1 * E, xt, B, V1, T1, E4);
-        MEDP_LAUNCH_CHECK("duett swap e->t");
-        MEDP_TRY(encoder_forward(w->time_enc[l], w, xt, B, T1, tt, base, ws, stream));                        // (model :91)
+        // event view -> time view (+ time embedding) (+ the time encoder's first ScaleNorm)                   (model :81,:90)
+        h_ready = fused && launch_swap_add_norm(xe, e_rn, (const float*)w->event_enc[l].g_final, sqrtf((float)et), temb,
+                                                (long long)T1 * V1 * E, (const float*)w->time_enc[l].g_attn, w->norm_eps, xt, base + ws.h, B,
+                                                V1, T1, E4, s) == 0;
+        if (!h_ready) {
+            axis_swap_add_kernel<<<swap_grid, 256, 0, s>>>(xe, e_rn, (const float*)w->event_enc[l].g_final, sqrtf((float)et), temb,
+                                                           (long long)T1 * V1 * E, xt, B, V1, T1, E4);
+            MEDP_LAUNCH_CHECK("duett swap e->t");
+        }
+        MEDP_TRY(encoder_forward(w->time_enc[l], w, xt, B, T1, tt, base, ws, stream, h_ready));               // (model :91)
         if (l + 1 < w->n_layers) {
             if (w->final_norm) {
                 MEDP_TRY(medp_scalenorm_fwd(xt, tt, w->time_enc[l].g_final, base + ws.h, tt, 1, rn, B * T1, tt, w->norm_eps, stream));
@@ -319,4 +525,52 @@ extern "C" int medp_duett_encode(const MedpDuettWeights* w, const float* xs_stat
     }
     if (tokens_bf16) MEDP_TRY(medp_cast_f32_bf16(tokens_f32, tt, tokens_bf16, tt, B * T1, tt, stream));
     return 0;
+}
+
+// ---- the embedding stage and the fused swap on their own (kernel-level parity checks and bench.py's per-kernel HBM table) ----------
+// stages: bit 0 = static encoder + fused psi build (writes xe_out fp32 [B,V+1,(T+1)E], h_out bf16 same shape, psi0_out optional);
+//         bit 1 = time embedding (writes temb_out fp32 [B,T+1,(V+1)E]).
+extern "C" int medp_duett_embed_fwd(const MedpDuettWeights* w, const float* xs_static, const float* xs_ts, const float* xs_times, int B, int T,
+                                    float* xe_out, void* h_out, float* temb_out, float* psi0_out, float* tab_workspace, int stages,
+                                    void* stream) {
+    MEDP_CHECK_ARG(w && xs_static && xs_ts && xs_times && B > 0 && T > 0, "duett_embed_fwd: bad argument");
+    MEDP_CHECK_ARG(w->d_embedding == 24 && w->d_hidden_embed == 64, "duett_embed_fwd: built for d_embedding 24 / hidden 64 (duett.py:50)");
+    hipStream_t s = (hipStream_t)stream;
+    const int V = w->n_vars, V1 = V + 1, T1 = T + 1, E = w->d_embedding, tt = E * V1;
+    if (stages & 1) {
+        MEDP_CHECK_ARG(xe_out && h_out && tab_workspace, "duett_embed_fwd: stage 1 needs xe_out, h_out and a B*E float workspace");
+        MEDP_CHECK_ARG((size_t)T1 * E * 4 <= 100 * 1024, "duett_embed_fwd: a (T+1)*E row must fit the LDS tile");
+        tab_encoder_kernel<<<B, 128, w->d_hidden_tab * sizeof(float), s>>>(xs_static, (const float*)w->tab_w0, (const float*)w->tab_b0,
+                                                                           (const float*)w->tab_bn_scale, (const float*)w->tab_bn_shift,
+                                                                           (const float*)w->tab_w4, (const float*)w->tab_b4, tab_workspace,
+                                                                           w->n_static, w->d_hidden_tab, E);
+        psi_embed_event_kernel<24, 64><<<dim3(V1, B), 128, (size_t)T1 * E * sizeof(float), s>>>(
+            xs_ts, (const float*)w->emb_w0, (const float*)w->emb_b0, (const float*)w->emb_bn_scale, (const float*)w->emb_bn_shift,
+            (const float*)w->emb_w4, (const float*)w->emb_b4, (const float*)w->n_obs_table, w->n_obs_rows, tab_workspace,
+            (const float*)w->special, (const float*)w->event_embedding, (const float*)w->event_enc[0].g_attn, w->norm_eps, xe_out,
+            (bf16_t*)h_out, psi0_out, B, T, V);
+        MEDP_LAUNCH_CHECK("duett_embed_fwd(psi)");
+    }
+    if (stages & 2) {
+        MEDP_CHECK_ARG(temb_out, "duett_embed_fwd: stage 2 needs temb_out");
+        time_embed_kernel<<<dim3((B * T1 + TE_ROWS - 1) / TE_ROWS, (tt + 255) / 256), 256, TE_ROWS * w->d_hidden_time * sizeof(float), s>>>(
+            xs_times, (const float*)w->time_w0, (const float*)w->time_b0, (const float*)w->time_bn_scale, (const float*)w->time_bn_shift,
+            (const float*)w->time_w3t, (const float*)w->time_b3, (const float*)w->rep_embedding, temb_out, B, T, w->d_hidden_time, tt);
+        MEDP_LAUNCH_CHECK("duett_embed_fwd(time)");
+    }
+    return 0;
+}
+
+// x_out[b][a2][a1][:] = in[b][a1][a2][:] * (rnorm ? rnorm[b][a1] * sqrt(A2*E) * g_prev : 1) + add ;  h_out = ScaleNorm(x_out) (bf16).
+// add: [A2, A1, E] table (add_batch_stride 0) or [B, A2, A1, E].
+extern "C" int medp_duett_swap_add_norm(const float* in, const float* rnorm, const float* g_prev, const float* add, long long add_batch_stride,
+                                        const float* g_norm, float norm_eps, float* x_out, void* h_out, int B, int A1, int A2, int E,
+                                        void* stream) {
+    MEDP_CHECK_ARG(in && add && g_norm && x_out && h_out && B > 0 && A1 > 0 && A2 > 0 && E > 0 && E % 4 == 0, "duett_swap_add_norm: bad argument");
+    MEDP_CHECK_ARG(!rnorm || g_prev, "duett_swap_add_norm: rnorm needs g_prev");
+    MEDP_CHECK_ARG((size_t)B * A1 * A2 * (E / 4) < (1ull << 31), "duett_swap_add_norm: too large");
+    const int rc = launch_swap_add_norm(in, rnorm, g_prev, sqrtf((float)A2 * E), add, add_batch_stride, g_norm, norm_eps, x_out, h_out, B, A1, A2,
+                                        E / 4, (hipStream_t)stream);
+    MEDP_CHECK_ARG(rc != 1, "duett_swap_add_norm: rows of more than 6400 floats are not built");
+    return rc;
 }

@@ -40,6 +40,8 @@ struct GemmParams {
     int ldr;
     int act;
     int out_bf16;
+    float* partial;     // split-K (small grids): blockIdx.y = K slice, raw fp32 partial sums go to partial[slice][M][N]
+    int nsplit;
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
@@ -68,13 +70,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const GemmParams p
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
 
-    const int nkt = (p.K + 63) >> 6;
+    // split-K: slice blockIdx.y owns K-tiles [kt_begin, kt_begin + nkt)
+    const int nkt_all = (p.K + 63) >> 6;
+    const int per_split = (nkt_all + p.nsplit - 1) / p.nsplit;
+    const int kt_begin = blockIdx.y * per_split;
+    const int nkt = max(0, min(nkt_all, kt_begin + per_split) - kt_begin);
     const bf16_t* zero = (const bf16_t*)g_zero16;
 
     auto stage = [&](int buf, int kt) {
         char* sa = smem + buf * STAGE;
         char* sb = sa + A_BYTES;
-        const int k0 = kt << 6;
+        const int k0 = (kt_begin + kt) << 6;
 #pragma unroll
         for (int i = 0; i < BM * 8 / 256; ++i) {
             const int qd = i * 256 + tid;
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const GemmParams p
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    stage(0, 0);
+    if (nkt > 0) stage(0, 0);
     MEDP_WAIT_LDS_DMA();
     __syncthreads();   // tile 0 landed (explicit wait) before any wave reads it
 
@@ -139,6 +145,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const GemmParams p
             const int n = n0 + wc * (BN / 2) + j * 16 + kq * 4;
             if (n >= p.N) continue;
             f32x4 v = acc[i][j];
+            if (p.partial) {          // split-K: raw partial sums; bias / activation / residual happen in splitk_finish_kernel
+                *(f32x4*)(p.partial + ((size_t)blockIdx.y * p.M + m) * p.N + n) = v;
+                continue;
+            }
             if (p.bias) {
                 const f32x4 b = *(const f32x4*)(p.bias + n);
                 v += b;
@@ -447,6 +457,30 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_v3_kernel(const GemmParam
     }
 }
 
+// split-K second pass: C = epi(sum_s partial[s]) — the slices are summed in ascending order (deterministic), then the same
+// epilogue as the one-pass kernel
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const GemmParams p) {
+    const int n4 = p.N >> 2;
+    const size_t total = (size_t)p.M * n4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int m = (int)(i / n4), n = (int)(i % n4) * 4;
+        f32x4 v = *(const f32x4*)(p.partial + (size_t)m * p.N + n);
+        for (int s = 1; s < p.nsplit; ++s) v += *(const f32x4*)(p.partial + ((size_t)s * p.M + m) * p.N + n);
+        if (p.bias) v += *(const f32x4*)(p.bias + n);
+        if (p.act == 1) v = gelu_erf4(v);
+        if (p.scale) v *= *(const f32x4*)(p.scale + n);
+        if (p.residual) v += *(const f32x4*)(p.residual + (size_t)m * p.ldr + n);
+        if (p.out_bf16) {
+            uint2 o;
+            o.x = pack_bf2(v[0], v[1]);
+            o.y = pack_bf2(v[2], v[3]);
+            *(uint2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+        } else {
+            *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = v;
+        }
+    }
+}
+
 template <int TAG>
 int launch_v3(const GemmParams& p, hipStream_t stream) {
     const int tiles = ((p.M + 255) / 256) * ((p.N + 127) / 128);
@@ -466,8 +500,13 @@ int launch(const GemmParams& p, hipStream_t stream) {
     MEDP_ONCE_PER_DEVICE({
         hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<BM, BN, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     });
-    gemm_bf16_nt_kernel<BM, BN, TAG><<<tiles, 256, LDS, stream>>>(p);
+    gemm_bf16_nt_kernel<BM, BN, TAG><<<dim3(tiles, p.nsplit), 256, LDS, stream>>>(p);
     MEDP_LAUNCH_CHECK("medp_gemm_bf16_nt");
+    if (p.partial) {
+        const size_t items = (size_t)p.M * (p.N >> 2);
+        splitk_finish_kernel<<<(int)min((size_t)2048, (items + 255) / 256), 256, 0, stream>>>(p);
+        MEDP_LAUNCH_CHECK("medp_gemm_bf16_nt(split-K finish)");
+    }
     return 0;
 }
 
@@ -554,9 +593,36 @@ extern "C" int medp_gemm_profile_collect(double* total_ms, long long* n_launches
     return 0;
 }
 
+// Split-K plan for SMALL grids (DuETT's skinny GEMMs: M = 3136 / 6208 rows, N = 72 / 512, K = 1176 / 2328 give 25-100 tiles
+// on 256 CUs with a 73-step K-loop each): K is cut into S slices so that tiles x S fills the chip; S = 1: no split.
+static int splitk_slices(int M, int N, int K) {
+    static const int force = [] { const char* e = getenv("MEDP_GEMM_SPLITK"); return e ? atoi(e) : -1; }();
+    const int tiles = ((M + 127) / 128) * (N <= 64 ? (N + 63) / 64 : (N + 127) / 128);
+    const int nkt = (K + 63) / 64;
+    if (force >= 0) return max(1, min(force, nkt));
+    if (tiles >= 128 || nkt < 8) return 1;
+    return max(1, min(min(256 / tiles, nkt / 4), 16));
+}
+
+extern "C" size_t medp_gemm_nt_workspace_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int S = splitk_slices(M, N, K);
+    return S > 1 ? (size_t)S * M * N * sizeof(float) : 0;
+}
+
+int medp_gemm_bf16_nt_tagged_ws(int tag, const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldw, int ldc,
+                                const float* bias, const float* scale, const float* residual, int ldr, int act, int out_bf16,
+                                float* workspace, size_t workspace_bytes, void* stream);
+
 int medp_gemm_bf16_nt_tagged(int tag, const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldw, int ldc,
                              const float* bias, const float* scale, const float* residual, int ldr, int act, int out_bf16,
                              void* stream) {
+    return medp_gemm_bf16_nt_tagged_ws(tag, A, W, C, M, N, K, lda, ldw, ldc, bias, scale, residual, ldr, act, out_bf16, nullptr, 0, stream);
+}
+
+int medp_gemm_bf16_nt_tagged_ws(int tag, const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldw, int ldc,
+                                const float* bias, const float* scale, const float* residual, int ldr, int act, int out_bf16,
+                                float* workspace, size_t workspace_bytes, void* stream) {
     MEDP_CHECK_ARG(A && W && C, "gemm: null operand");
     MEDP_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
     MEDP_CHECK_ARG(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0, "gemm: K, lda, ldw must be multiples of 8 (16-B chunks)");
@@ -566,8 +632,17 @@ int medp_gemm_bf16_nt_tagged(int tag, const void* A, const void* W, void* C, int
     MEDP_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0,
                    "gemm: operands must be 16-byte aligned");
     MEDP_CHECK_ARG(act == 0 || act == 1, "gemm: act must be 0 (none) or 1 (gelu)");
-    GemmParams p{(const bf16_t*)A, (const bf16_t*)W, C, M, N, K, lda, ldw, ldc, bias, scale, residual, ldr, act, out_bf16};
+    GemmParams p{(const bf16_t*)A, (const bf16_t*)W, C, M, N, K, lda, ldw, ldc, bias, scale, residual, ldr, act, out_bf16, nullptr, 1};
     hipStream_t s = (hipStream_t)stream;
+    if (workspace && tag != 1) {
+        const int S = splitk_slices(M, N, K);
+        if (S > 1) {
+            MEDP_CHECK_ARG(workspace_bytes >= (size_t)S * M * N * sizeof(float), "gemm: split-K workspace too small (medp_gemm_nt_workspace_bytes)");
+            p.partial = workspace;
+            p.nsplit = S;
+            return N <= 64 ? launch<128, 64, 0>(p, s) : launch<128, 128, 0>(p, s);
+        }
+    }
     static const int force = [] { const char* e = getenv("MEDP_GEMM_VARIANT"); return e ? atoi(e) : 0; }();   // 1 = v1, 2 = v2 (A/B tests)
     const bool use_v2 = force == 2;
     const bool use_v3 = force == 3 || (force == 0 && M >= 2048 && N >= 256);
@@ -621,4 +696,11 @@ extern "C" int medp_gemm_bf16_nt(const void* A, const void* W, void* C, int M, i
                                  const float* bias, const float* scale, const float* residual, int ldr, int act, int out_bf16,
                                  void* stream) {
     return medp_gemm_bf16_nt_tagged(0, A, W, C, M, N, K, lda, ldw, ldc, bias, scale, residual, ldr, act, out_bf16, stream);
+}
+
+extern "C" int medp_gemm_bf16_nt_ws(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldw, int ldc,
+                                    const float* bias, const float* scale, const float* residual, int ldr, int act, int out_bf16,
+                                    float* workspace, size_t workspace_bytes, void* stream) {
+    return medp_gemm_bf16_nt_tagged_ws(0, A, W, C, M, N, K, lda, ldw, ldc, bias, scale, residual, ldr, act, out_bf16, workspace,
+                                       workspace_bytes, stream);
 }

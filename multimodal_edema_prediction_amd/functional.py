@@ -48,8 +48,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, scale=None, residual=None,
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=a.device)
     r2 = _2d(residual) if residual is not None else None
-    check(lib().medp_gemm_bf16_nt(ptr(a2), ptr(w2), ptr(out), M, N, K, _ld(a2), _ld(w2), _ld(out), ptr(bias), ptr(scale),
-                                   ptr(r2), _ld(r2) if r2 is not None else 0, act, int(out.dtype == BF16), stream()), "gemm")
+    wsb = lib().medp_gemm_nt_workspace_bytes(M, N, K)          # > 0: a small grid that is split along K (deterministic two-pass sum)
+    ws = torch.empty(wsb // 4, dtype=F32, device=a.device) if wsb else None
+    check(lib().medp_gemm_bf16_nt_ws(ptr(a2), ptr(w2), ptr(out), M, N, K, _ld(a2), _ld(w2), _ld(out), ptr(bias), ptr(scale),
+                                      ptr(r2), _ld(r2) if r2 is not None else 0, act, int(out.dtype == BF16), ptr(ws), wsb, stream()), "gemm")
     return out
 
 

@@ -1,0 +1,82 @@
+"""The fused DuETT front end (csrc/duett.hip): `medp_duett_embed_fwd` — psi built directly in the event view with the event
+embedding added and the first ScaleNorm applied, and the time embedding — and `medp_duett_swap_add_norm` (axis swap + positional
+add + the next encoder's ScaleNorm in one pass), against the CPU oracle (oracle/duett_ref.py, pinned by the reference's fixtures)
+and against the separate launches they replace (bit-identical ScaleNorm)."""
+import ctypes
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+from multimodal_edema_prediction_amd import functional as Fn  # noqa: E402
+from multimodal_edema_prediction_amd.abi import check, lib, ptr, stream  # noqa: E402
+
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("B,T,V", [(8, 32, 16), (5, 96, 48)])
+def test_embed_stage_against_oracle(B, T, V):
+    from multimodal_edema_prediction_amd.cohort import CohortCfg, make_batch
+    from multimodal_edema_prediction_amd.main_architecture_duett import load_duett_backbone
+    from oracle import duett_ref
+    DS, E = 8, 24
+    torch.manual_seed(0)
+    m = load_duett_backbone("synthetic", d_static_num=DS, d_time_series_num=V, n_timesteps=T, freeze=True)
+    with torch.no_grad():                                   # non-trivial BatchNorm statistics and norm gains
+        for n, b in m.named_buffers():
+            if n.endswith("running_mean"):
+                b.copy_(0.1 * torch.randn_like(b))
+            elif n.endswith("running_var"):
+                b.copy_(0.5 + torch.rand_like(b))
+        m.event_transformers[0].layers[0][0][0].g.fill_(1.3)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV)
+    batch = make_batch(CohortCfg(n_timesteps=T, n_vars=V, d_static=DS, image_size=32), 7, B, mode="student")
+    x = (batch["x_ts"], batch["x_static"], list(batch["bin_ends"]))
+    xin = duett_ref.feats_to_input(x, max_len=T)
+    _, inter = duett_ref.encode(sd, duett_ref.DuettCfg(d_static_num=DS, d_time_series_num=V, n_timesteps=T), xin, return_intermediates=True)
+    psi0, temb_ref = inter["psi0"], inter["time_emb"]                                   # [B,T+1,V+1,E], [B,T+1,(V+1)E]
+    xe_ref = psi0.transpose(1, 2).flatten(2) + sd["full_event_embedding.weight"]          # model :80
+    g = sd["event_transformers.0.layers.0.0.0.g"]
+    h_ref = torch.nn.functional.normalize(xe_ref, dim=-1) * xe_ref.shape[-1] ** 0.5 * g
+
+    xs_static, xs_ts, xs_times, _ = m.feats_to_input(x, B)
+    w = m._prepare()[0]
+    T1, V1 = T + 1, V + 1
+    xe = torch.empty((B, V1, T1 * E), device=DEV)
+    h = torch.empty((B, V1, T1 * E), device=DEV, dtype=torch.bfloat16)
+    temb = torch.empty((B, T1, V1 * E), device=DEV)
+    p0 = torch.empty((B, T1, V1, E), device=DEV)
+    tab = torch.empty((B, E), device=DEV)
+    check(lib().medp_duett_embed_fwd(ctypes.byref(w), ptr(xs_static), ptr(xs_ts), ptr(xs_times), B, T, ptr(xe), ptr(h), ptr(temb), ptr(p0),
+                                     ptr(tab), 3, stream()), "duett_embed_fwd")
+    assert float((p0.cpu() - psi0).abs().max()) < 2e-5
+    assert float((xe.cpu() - xe_ref).abs().max()) < 2e-5
+    assert float((temb.cpu() - temb_ref).abs().max()) < 2e-5
+    assert float((h.float().cpu() - h_ref).abs().max()) < 8e-3 * float(h_ref.abs().max())            # bf16 output
+    assert torch.equal(h, Fn.scalenorm(xe, m.event_transformers[0].layers[0][0][0].g))               # == the separate launch, bit for bit
+
+
+@pytest.mark.parametrize("B,A1,A2", [(3, 33, 17), (4, 97, 49), (2, 49, 97), (1, 257, 97)])
+@pytest.mark.parametrize("pending_norm,batched_add", [(False, False), (True, True)])
+def test_swap_add_norm(B, A1, A2, pending_norm, batched_add):
+    E = 24
+    g0 = torch.Generator().manual_seed(B * 1000 + A1)
+    x = torch.randn(B, A1, A2, E, generator=g0)
+    rn = (0.5 + torch.rand(B * A1, generator=g0)) if pending_norm else None
+    gp, gn = torch.tensor([1.2]), torch.tensor([0.8])
+    add = torch.randn((B, A2, A1, E) if batched_add else (A2, A1, E), generator=g0)
+    sc = (rn.view(B, A1, 1, 1) * ((A2 * E) ** 0.5 * gp)) if pending_norm else 1.0
+    x_ref = (x * sc).transpose(1, 2) + add                                             # [B, A2, A1, E]
+    xo = torch.empty((B, A2, A1 * E), device=DEV)
+    ho = torch.empty((B, A2, A1 * E), device=DEV, dtype=torch.bfloat16)
+    check(lib().medp_duett_swap_add_norm(ptr(x.to(DEV)), ptr(rn.to(DEV)) if pending_norm else None, ptr(gp.to(DEV)), ptr(add.to(DEV)),
+                                         A2 * A1 * E if batched_add else 0, ptr(gn.to(DEV)), 1e-12, ptr(xo), ptr(ho), B, A1, A2, E, stream()),
+          "swap_add_norm")
+    ref = x_ref.reshape(B, A2, A1 * E)
+    assert float((xo.cpu() - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) + 1e-6
+    assert torch.equal(ho, Fn.scalenorm(xo, gn.to(DEV)))                               # the fused norm == medp_scalenorm_fwd of its x

@@ -72,6 +72,29 @@ def test_gemm_epilogue_and_strides():
     assert_close(x, (a.double() @ w.double().T + bias.double()) * scale.double() + res.double(), 2e-4, 3e-4, "gemm in-place residual")
 
 
+@pytest.mark.parametrize("M,N,K", [(3136, 512, 2328), (6208, 72, 1176), (3136, 72, 2328), (777, 100, 1160)])
+def test_gemm_split_k_small_grids(M, N, K):
+    """DuETT's skinny GEMMs fill 25-100 of 256 CUs with one tile each: they are split along K (medp_gemm_bf16_nt_ws) — partial
+    sums in a caller workspace, summed in a fixed order by a second pass that applies the epilogue.  Same values as the fp64
+    reference, every epilogue form, in-place residual, and bit-identical from run to run (no atomics)."""
+    from multimodal_edema_prediction_amd.abi import lib
+    assert lib().medp_gemm_nt_workspace_bytes(M, N, K) > 0                      # these shapes do take the split path
+    assert lib().medp_gemm_nt_workspace_bytes(16448, 768, 768) == 0              # a full grid does not
+    a = bf_round(rnd(M, K, seed=11))
+    w = bf_round(rnd(N, K, seed=12) / math.sqrt(K))
+    bias, res = rnd(N, seed=13), rnd(M, N, seed=14)
+    ad, wd = a.to(DEV).bfloat16(), w.to(DEV).bfloat16()
+    want = a.double() @ w.double().T
+    assert_close(Fn.gemm(ad, wd), want, 1e-4, 2e-4, "split-K plain")
+    g1 = Fn.gemm(ad, wd, bias=bias.to(DEV), act=1, out_dtype=torch.bfloat16)
+    g2 = Fn.gemm(ad, wd, bias=bias.to(DEV), act=1, out_dtype=torch.bfloat16)
+    assert torch.equal(g1, g2)
+    assert_close(g1, torch.nn.functional.gelu(want + bias.double()), 8e-3, 8e-3, "split-K bias+gelu -> bf16")
+    x = res.to(DEV).clone()
+    Fn.gemm(ad, wd, residual=x, out=x)                                           # in place: C = A W^T + C
+    assert_close(x, want + res.double(), 1e-4, 2e-4, "split-K in-place residual")
+
+
 def test_gemm_rejects_bad_arguments():
     a = torch.zeros(8, 12, device=DEV, dtype=torch.bfloat16)
     w = torch.zeros(8, 12, device=DEV, dtype=torch.bfloat16)
