@@ -70,6 +70,11 @@ int medp_gemm_profile_collect(double* host_total_ms, long long* host_n_launches,
  * q/k/v: [B*S, ...] rows with strides ld*, head h at column h*64.  o: [B*S, H*64]. */
 int medp_attn_fwd_dh64(const void* q, const void* k, const void* v, void* o, int B, int S, int H, int ldq, int ldk,
                        int ldv, int ldo, float scale, void* stream);
+/* Dense self-attention for small head dims (dh <= 16, dh % 4 == 0, N <= 272) on the matrix cores: DuETT's event / time axis
+ * encoders (x_transformers Encoder, duett/duett.py:95-105: 2 heads of dim 12 over V+1 / T+1 tokens, no mask), inference form.
+ * qkv: fp32 rows [B*N, ld] holding q | k | v column blocks of H*dh each (the fused QKV GEMM's output); o: bf16 [B*N, ldo].
+ * Returns -2 (nothing launched) for shapes it is not built for: the caller then uses medp_attn_small_fwd. */
+int medp_attn_dh16_fwd(const float* qkv, int ld, void* o_bf16, int ldo, int B, int N, int H, int dh, float scale, void* stream);
 /* Training form (--unfreeze_cxr, run.py:184-187): the same forward that also writes lse[B,H,S], the log2-domain logsumexp of the
  * scaled scores, and the flash backward that consumes it.  prep: dsum[b,h,s] = <dout, o> and the bf16 copy of dout.
  * bwd: dq/dk/dv fp32 with row stride ldd (e.g. the three column blocks of one [B*S, 3*H*64] buffer); q/k/v/dout_bf16 bf16. */
@@ -179,6 +184,9 @@ typedef struct {
     float norm_eps;
     /* per-variable embedding MLPs stacked over V: Linear(2,64) -> ReLU -> BN -> Linear(64,E)  (duett.py:84-86) */
     const void *emb_w0, *emb_b0, *emb_bn_scale, *emb_bn_shift, *emb_w4, *emb_b4;   /* fp32 [V,64,2] [V,64] [V,64] [V,64] [V,E,64] [V,E] */
+    /* the same per-variable MLPs in the layout the fused embed kernel reads with SCALAR loads (weights are uniform over a
+     * workgroup): emb_l0 fp32 [V,64,8] = (w0[j][0], w0[j][1], b0[j], bn_scale[j], bn_shift[j], 0, 0, 0); emb_w4t fp32 [V,64,E] = w4 transposed */
+    const void *emb_l0, *emb_w4t;
     const void* n_obs_table;      /* fp32 [n_obs_rows] (n_obs_embedding.weight[:,0]) */
     const void *tab_w0, *tab_b0, *tab_bn_scale, *tab_bn_shift, *tab_w4, *tab_b4;   /* tab_encoder (duett.py:124-125) */
     const void* special;          /* fp32 [8, E] special_embeddings */

@@ -38,7 +38,7 @@ class MedpDuettWeights(ctypes.Structure):
     _fields_ = ([(n, I) for n in ("n_vars", "n_static", "d_embedding", "n_heads", "n_layers", "d_ff", "d_hidden_embed",
                                   "d_hidden_tab", "d_hidden_time", "n_obs_rows", "final_norm")]
                 + [("norm_eps", F)]
-                + [(n, P) for n in ("emb_w0", "emb_b0", "emb_bn_scale", "emb_bn_shift", "emb_w4", "emb_b4", "n_obs_table",
+                + [(n, P) for n in ("emb_w0", "emb_b0", "emb_bn_scale", "emb_bn_shift", "emb_w4", "emb_b4", "emb_l0", "emb_w4t", "n_obs_table",
                                     "tab_w0", "tab_b0", "tab_bn_scale", "tab_bn_shift", "tab_w4", "tab_b4", "special",
                                     "time_w0", "time_b0", "time_bn_scale", "time_bn_shift", "time_w3t", "time_b3",
                                     "rep_embedding", "event_embedding")]
@@ -62,6 +62,7 @@ SIGNATURES = {
     "medp_gemm_profile_enable": (I, [I]),
     "medp_gemm_profile_collect": (I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_longlong), ctypes.POINTER(ctypes.c_double)]),
     "medp_attn_fwd_dh64": (I, [P, P, P, P, I, I, I, I, I, I, I, F, P]),
+    "medp_attn_dh16_fwd": (I, [P, I, P, I, I, I, I, I, F, P]),
     "medp_attn_fwd_dh64_lse": (I, [P, P, P, P, P, I, I, I, I, I, I, I, F, P]),
     "medp_attn_bwd_dh64_prep": (I, [P, I, P, I, P, I, P, I, I, I, P]),
     "medp_attn_bwd_dh64": (I, [P, P, P, I, P, I, P, P, P, P, P, I, I, I, I, F, P]),

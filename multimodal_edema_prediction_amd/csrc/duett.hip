@@ -195,30 +195,24 @@ __global__ __launch_bounds__(256) void axis_swap_add_kernel(const float* __restr
 // The row's sum of squares is taken by wave 0 in the lane / chunk order of scalenorm_fwd_reg_kernel, so `h` is bit-identical to
 // what the separate ScaleNorm launch produced.
 template <int E, int HD>
-__global__ __launch_bounds__(128) void psi_embed_event_kernel(const float* __restrict__ xs_ts, const float* __restrict__ w0,
-                                                              const float* __restrict__ b0, const float* __restrict__ bs,
-                                                              const float* __restrict__ bsh, const float* __restrict__ w4,
-                                                              const float* __restrict__ b4, const float* __restrict__ nobs_table,
-                                                              int nobs_rows, const float* __restrict__ tab_out,
-                                                              const float* __restrict__ special, const float* __restrict__ event_emb,
-                                                              const float* __restrict__ g_norm, float norm_eps, float* __restrict__ xe,
-                                                              bf16_t* __restrict__ h, float* __restrict__ psi0_out, int B, int T, int V) {
-    extern __shared__ __attribute__((aligned(16))) float tile[];          // [(T+1)*E] the row, then weights
-    __shared__ __attribute__((aligned(16))) float sw0[HD * 2], sb0[HD], ss_[HD], ssh[HD], sw4t[HD * E], sb4[E];   // sw4t = second Linear TRANSPOSED [HD][E]
+__global__ __launch_bounds__(128) void psi_embed_event_kernel(const float* __restrict__ xs_ts, const float* __restrict__ l0,
+                                                              const float* __restrict__ w4t, const float* __restrict__ b4,
+                                                              const float* __restrict__ nobs_table, int nobs_rows,
+                                                              const float* __restrict__ tab_out, const float* __restrict__ special,
+                                                              const float* __restrict__ event_emb, const float* __restrict__ g_norm,
+                                                              float norm_eps, float* __restrict__ xe, bf16_t* __restrict__ h,
+                                                              float* __restrict__ psi0_out, int B, int T, int V) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];          // [(T+1)*E] the row
     __shared__ float s_rn;
     const int v = blockIdx.x, b = blockIdx.y;
     const int T1 = T + 1, F = 2 * V + 1, D = T1 * E, D4 = D >> 2;
-    if (v < V) {
-        for (int i = threadIdx.x; i < HD * 2; i += 128) sw0[i] = w0[(size_t)v * HD * 2 + i];
-        for (int i = threadIdx.x; i < HD; i += 128) {
-            sb0[i] = b0[(size_t)v * HD + i];
-            ss_[i] = bs[(size_t)v * HD + i];
-            ssh[i] = bsh[(size_t)v * HD + i];
-        }
-        for (int i = threadIdx.x; i < E * HD; i += 128) sw4t[(i % HD) * E + i / HD] = w4[(size_t)v * E * HD + i];   // [e][j] -> [j][e]
-        for (int i = threadIdx.x; i < E; i += 128) sb4[i] = b4[(size_t)v * E + i];
-    }
-    __syncthreads();
+    // The variable's MLP weights are the same for every lane of the workgroup: they are read straight from global memory at
+    // wave-uniform addresses, i.e. by SCALAR loads into SGPRs (one s_load_dwordx8 of layer 0 and three of layer 1 per hidden
+    // unit), and enter the FMAs as scalar operands.  The first form kept them in LDS: 11 LDS reads per hidden unit and lane
+    // made the one LDS pipe of the CU, shared by its four SIMDs, the bound (50 us at cfg3 against ~10 us of VALU work).
+    const float* l0v = l0 + (size_t)(v < V ? v : 0) * HD * 8;
+    const float* w4v = w4t + (size_t)(v < V ? v : 0) * HD * E;
+    const float* b4v = b4 + (size_t)(v < V ? v : 0) * E;
     for (int t = threadIdx.x; t < T1; t += 128) {
         float out[E];
         const float* src = nullptr;
@@ -238,16 +232,14 @@ __global__ __launch_bounds__(128) void psi_embed_event_kernel(const float* __res
                     const int idx = min(max((int)cnt, 0), nobs_rows - 1);
                     const float val = row[v], nob = nobs_table[idx];
 #pragma unroll
-                    for (int e = 0; e < E; ++e) out[e] = sb4[e];
-#pragma unroll 8
+                    for (int e = 0; e < E; ++e) out[e] = b4v[e];
+#pragma unroll 4
                     for (int j = 0; j < HD; ++j) {
-                        const float hj = fmaxf(sw0[2 * j] * val + sw0[2 * j + 1] * nob + sb0[j], 0.f) * ss_[j] + ssh[j];
-                        const float4* wj = (const float4*)(sw4t + j * E);       // one broadcast 16-B read per 4 outputs, packed FMAs
+                        const float* lj = l0v + j * 8;
+                        const float hj = fmaxf(lj[0] * val + lj[1] * nob + lj[2], 0.f) * lj[3] + lj[4];
+                        const float* wj = w4v + j * E;
 #pragma unroll
-                        for (int e4 = 0; e4 < E / 4; ++e4) {
-                            const float4 w = wj[e4];
-                            out[4 * e4] += w.x * hj; out[4 * e4 + 1] += w.y * hj; out[4 * e4 + 2] += w.z * hj; out[4 * e4 + 3] += w.w * hj;
-                        }
+                        for (int e = 0; e < E; ++e) out[e] += wj[e] * hj;
                     }
                 }
             }
@@ -402,8 +394,13 @@ int encoder_forward(const MedpEncoderWeights& e, const MedpDuettWeights* w, floa
     if (!h_ready)      // else: the producer of x (embed / swap kernel) has written ScaleNorm(x) to ws.h already
         MEDP_TRY(medp_scalenorm_fwd(x, D, e.g_attn, h, D, 1, nullptr, M, D, w->norm_eps, stream));
     MEDP_TRY(medp_gemm_bf16_nt_ws(h, e.qkv_w, qkv, M, 3 * E, D, D, D, 3 * E, nullptr, nullptr, nullptr, 0, 0, 0, sp, ws.split_bytes, stream));
-    MEDP_TRY(medp_attn_small_fwd(qkv, 3 * E, (long long)N * 3 * E, qkv + E, qkv + 2 * E, 3 * E, (long long)N * 3 * E, o, E, 1, nullptr,
-                                 B, N, N, H, dh, 1.0f / sqrtf((float)dh), 0.f, 0u, 0u, stream));
+    // both axes' attention on the matrix cores (attention_dh16.hip); shapes it is not built for take the fp32 VALU kernel
+    static const bool mfma_attn = [] { const char* e2 = getenv("MEDP_DUETT_MFMA_ATTN"); return !e2 || atoi(e2) != 0; }();
+    int arc = mfma_attn ? medp_attn_dh16_fwd(qkv, 3 * E, o, E, B, N, H, dh, 1.0f / sqrtf((float)dh), stream) : -2;
+    if (arc == -2)
+        arc = medp_attn_small_fwd(qkv, 3 * E, (long long)N * 3 * E, qkv + E, qkv + 2 * E, 3 * E, (long long)N * 3 * E, o, E, 1, nullptr, B, N,
+                                  N, H, dh, 1.0f / sqrtf((float)dh), 0.f, 0u, 0u, stream);
+    MEDP_TRY(arc);
     MEDP_TRY(medp_gemm_bf16_nt_ws(o, e.out_w, x, M, D, E, E, E, D, nullptr, nullptr, x, D, 0, 0, sp, ws.split_bytes, stream));
     MEDP_TRY(medp_scalenorm_fwd(x, D, e.g_ff, h, D, 1, nullptr, M, D, w->norm_eps, stream));
     MEDP_TRY(medp_gemm_bf16_nt_ws(h, e.ff1_w, f, M, w->d_ff, D, D, D, w->d_ff, e.ff1_b, nullptr, nullptr, 0, 1, 1, sp, ws.split_bytes, stream));
@@ -452,10 +449,11 @@ extern "C" int medp_duett_encode(const MedpDuettWeights* w, const float* xs_stat
     static const bool fused = [] { const char* e = getenv("MEDP_DUETT_FUSED"); return !e || atoi(e) != 0; }();
     const int swap_grid = grid_for((size_t)B * T1 * V1 * E4);
     if (fused) {
+        MEDP_CHECK_ARG(w->emb_l0 && w->emb_w4t, "duett_encode: emb_l0 / emb_w4t (scalar-load weight layout) missing");
         psi_embed_event_kernel<24, 64><<<dim3(V1, B), 128, (size_t)T1 * E * sizeof(float), s>>>(
-            xs_ts, (const float*)w->emb_w0, (const float*)w->emb_b0, (const float*)w->emb_bn_scale, (const float*)w->emb_bn_shift,
-            (const float*)w->emb_w4, (const float*)w->emb_b4, (const float*)w->n_obs_table, w->n_obs_rows, tab, (const float*)w->special,
-            (const float*)w->event_embedding, (const float*)w->event_enc[0].g_attn, w->norm_eps, xe, (bf16_t*)(base + ws.h), psi0_out, B, T, V);
+            xs_ts, (const float*)w->emb_l0, (const float*)w->emb_w4t, (const float*)w->emb_b4, (const float*)w->n_obs_table, w->n_obs_rows, tab,
+            (const float*)w->special, (const float*)w->event_embedding, (const float*)w->event_enc[0].g_attn, w->norm_eps, xe,
+            (bf16_t*)(base + ws.h), psi0_out, B, T, V);
         MEDP_LAUNCH_CHECK("duett psi_embed_event");
     } else {
         psi_embed_kernel<24, 64><<<dim3((B * T1 + 255) / 256, V1), 256, 0, s>>>(
@@ -544,11 +542,11 @@ extern "C" int medp_duett_embed_fwd(const MedpDuettWeights* w, const float* xs_s
                                                                            (const float*)w->tab_bn_scale, (const float*)w->tab_bn_shift,
                                                                            (const float*)w->tab_w4, (const float*)w->tab_b4, tab_workspace,
                                                                            w->n_static, w->d_hidden_tab, E);
+        MEDP_CHECK_ARG(w->emb_l0 && w->emb_w4t, "duett_embed_fwd: emb_l0 / emb_w4t (scalar-load weight layout) missing");
         psi_embed_event_kernel<24, 64><<<dim3(V1, B), 128, (size_t)T1 * E * sizeof(float), s>>>(
-            xs_ts, (const float*)w->emb_w0, (const float*)w->emb_b0, (const float*)w->emb_bn_scale, (const float*)w->emb_bn_shift,
-            (const float*)w->emb_w4, (const float*)w->emb_b4, (const float*)w->n_obs_table, w->n_obs_rows, tab_workspace,
-            (const float*)w->special, (const float*)w->event_embedding, (const float*)w->event_enc[0].g_attn, w->norm_eps, xe_out,
-            (bf16_t*)h_out, psi0_out, B, T, V);
+            xs_ts, (const float*)w->emb_l0, (const float*)w->emb_w4t, (const float*)w->emb_b4, (const float*)w->n_obs_table, w->n_obs_rows,
+            tab_workspace, (const float*)w->special, (const float*)w->event_embedding, (const float*)w->event_enc[0].g_attn, w->norm_eps,
+            xe_out, (bf16_t*)h_out, psi0_out, B, T, V);
         MEDP_LAUNCH_CHECK("duett_embed_fwd(psi)");
     }
     if (stages & 2) {

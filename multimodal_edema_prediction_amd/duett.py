@@ -322,6 +322,13 @@ class Model(nn.Module):
         w.emb_bn_shift = f32(torch.stack([b for _, b in folded]))
         w.emb_w4 = f32(torch.stack([m[4].weight for m in el]))
         w.emb_b4 = f32(torch.stack([m[4].bias for m in el]))
+        # scalar-load layout of the same MLPs for the fused embed kernel (include/medp_hip.h)
+        w0s, b0s = torch.stack([m[0].weight for m in el]).detach(), torch.stack([m[0].bias for m in el]).detach()
+        l0 = torch.zeros((V, w0s.shape[1], 8), dtype=torch.float32, device=w0s.device)
+        l0[..., 0:2], l0[..., 2] = w0s, b0s
+        l0[..., 3], l0[..., 4] = torch.stack([s for s, _ in folded]), torch.stack([b for _, b in folded])
+        w.emb_l0 = f32(l0)
+        w.emb_w4t = f32(torch.stack([m[4].weight for m in el]).transpose(1, 2))
         w.n_obs_table = f32(self.n_obs_embedding.weight[:, 0])
         te = self.tab_encoder
         ts_, tb_ = te[3].folded()

@@ -74,9 +74,32 @@ def test_swap_add_norm(B, A1, A2, pending_norm, batched_add):
     x_ref = (x * sc).transpose(1, 2) + add                                             # [B, A2, A1, E]
     xo = torch.empty((B, A2, A1 * E), device=DEV)
     ho = torch.empty((B, A2, A1 * E), device=DEV, dtype=torch.bfloat16)
-    check(lib().medp_duett_swap_add_norm(ptr(x.to(DEV)), ptr(rn.to(DEV)) if pending_norm else None, ptr(gp.to(DEV)), ptr(add.to(DEV)),
-                                         A2 * A1 * E if batched_add else 0, ptr(gn.to(DEV)), 1e-12, ptr(xo), ptr(ho), B, A1, A2, E, stream()),
-          "swap_add_norm")
+    xd, rd, gpd, ad, gnd = x.to(DEV), (rn.to(DEV) if pending_norm else None), gp.to(DEV), add.to(DEV), gn.to(DEV)   # kept alive past the launch
+    check(lib().medp_duett_swap_add_norm(ptr(xd), ptr(rd), ptr(gpd), ptr(ad), A2 * A1 * E if batched_add else 0, ptr(gnd), 1e-12, ptr(xo),
+                                         ptr(ho), B, A1, A2, E, stream()), "swap_add_norm")
     ref = x_ref.reshape(B, A2, A1 * E)
     assert float((xo.cpu() - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) + 1e-6
-    assert torch.equal(ho, Fn.scalenorm(xo, gn.to(DEV)))                               # the fused norm == medp_scalenorm_fwd of its x
+    assert torch.equal(ho, Fn.scalenorm(xo, gnd))                               # the fused norm == medp_scalenorm_fwd of its x
+
+
+@pytest.mark.parametrize("B,N,H,dh", [(3, 17, 2, 12), (2, 33, 2, 12), (4, 49, 2, 12), (5, 97, 2, 12), (2, 257, 2, 12), (2, 100, 3, 16), (1, 16, 1, 4)])
+def test_attn_dh16_mfma_forward(B, N, H, dh):
+    """DuETT's attention on the matrix cores (medp_attn_dh16_fwd) against an fp64 softmax(QK^T/sqrt(dh))V on the same bf16-rounded
+    operands (tolerance: bf16 probabilities and output, 8e-3 of the output range) and against the fp32 VALU kernel it replaces."""
+    D = H * dh
+    g0 = torch.Generator().manual_seed(N)
+    qkv = torch.randn(B, N, 3 * D, generator=g0) * 1.5
+    qd = qkv.to(DEV)
+    o = torch.full((B, N, D), float("nan"), device=DEV, dtype=torch.bfloat16)
+    rc = lib().medp_attn_dh16_fwd(ptr(qd), 3 * D, ptr(o), D, B, N, H, dh, dh ** -0.5, stream())
+    check(rc, "attn_dh16_fwd")
+    r = qkv.to(torch.bfloat16).double().view(B, N, 3, H, dh)
+    q, k, v = r[:, :, 0].transpose(1, 2), r[:, :, 1].transpose(1, 2), r[:, :, 2].transpose(1, 2)
+    want = (torch.softmax(q @ k.transpose(-1, -2) * dh ** -0.5, -1) @ v).transpose(1, 2).reshape(B, N, D)
+    got = o.float().cpu().double()
+    assert torch.isfinite(got).all()
+    assert float((got - want).abs().max()) < 8e-3 * max(1.0, float(want.abs().max()))
+    old = Fn.attn_small_fwd(qd[..., :D], qd[..., D:2 * D], qd[..., 2 * D:], B, N, N, H, dh, dh ** -0.5, q_batch_stride=N * 3 * D,
+                            kv_batch_stride=N * 3 * D, out_dtype=torch.bfloat16)
+    assert float((old.float() - o.float()).abs().max()) < 3e-2 * max(1.0, float(want.abs().max()))
+    assert lib().medp_attn_dh16_fwd(ptr(qd), 3 * D, ptr(o), D, B, N, H, 20, 0.2, stream()) == -2          # not built: caller falls back
