@@ -200,7 +200,7 @@ typedef struct {
 /* The embedding stage of medp_duett_encode on its own (model :41-69; kernel-level parity and the per-kernel HBM table of bench.py).
  * stages bit 0: static encoder + FUSED psi build: psi (model :45-66) is produced directly in the EVENT view with the event
  *   embedding added (model :80) and the event encoder's first ScaleNorm applied: xe_out fp32 [B, V+1, (T+1)E], h_out bf16 (same
- *   shape), psi0_out (optional) psi in the time view [B, T+1, V+1, E] before the add; tab_workspace: B*E floats.
+ *   shape), psi0_out (optional) psi in the time view [B, T+1, V+1, E] before the add; tab_workspace: unused (may be NULL).
  * stages bit 1: time embedding cve(xs_times) with the REP row appended (model :67-69): temb_out fp32 [B, T+1, (V+1)E]. */
 int medp_duett_embed_fwd(const MedpDuettWeights* host_w, const float* xs_static, const float* xs_ts, const float* xs_times, int B, int T,
                          float* xe_out, void* h_out_bf16, float* temb_out, float* psi0_out, float* tab_workspace, int stages, void* stream);

@@ -194,17 +194,24 @@ __global__ __launch_bounds__(256) void axis_swap_add_kernel(const float* __restr
 // It replaces psi_embed + axis_swap_add + scalenorm of layer 0 (psi0 is never written; reads 2.4 MB, writes |psi| fp32 + bf16).
 // The row's sum of squares is taken by wave 0 in the lane / chunk order of scalenorm_fwd_reg_kernel, so `h` is bit-identical to
 // what the separate ScaleNorm launch produced.
+struct TabWeights {
+    const float *xs, *w0, *b0, *s, *sh, *w4, *b4;
+    int Ds, Hd;
+};
 template <int E, int HD>
 __global__ __launch_bounds__(128) void psi_embed_event_kernel(const float* __restrict__ xs_ts, const float* __restrict__ l0,
                                                               const float* __restrict__ w4t, const float* __restrict__ b4,
-                                                              const float* __restrict__ nobs_table, int nobs_rows,
-                                                              const float* __restrict__ tab_out, const float* __restrict__ special,
+                                                              const float* __restrict__ nobs_table, int nobs_rows, const TabWeights tw,
+                                                              const float* __restrict__ special,
                                                               const float* __restrict__ event_emb, const float* __restrict__ g_norm,
                                                               float norm_eps, float* __restrict__ xe, bf16_t* __restrict__ h,
                                                               float* __restrict__ psi0_out, int B, int T, int V) {
     extern __shared__ __attribute__((aligned(16))) float tile[];          // [(T+1)*E] the row
-    __shared__ float s_rn;
-    const int v = blockIdx.x, b = blockIdx.y;
+    __shared__ float s_rn, s_tab[E], s_hid[256];
+    // grid (B, V+1): the batch index is the FAST block index, so the workgroups resident on a CU at any time share one or two
+    // variables — their weights (7.4 KB per variable) then stay in the 16-KB scalar cache; with the variable as the fast index
+    // every resident workgroup streamed a different variable's weights through it.
+    const int b = blockIdx.x, v = blockIdx.y;
     const int T1 = T + 1, F = 2 * V + 1, D = T1 * E, D4 = D >> 2;
     // The variable's MLP weights are the same for every lane of the workgroup: they are read straight from global memory at
     // wave-uniform addresses, i.e. by SCALAR loads into SGPRs (one s_load_dwordx8 of layer 0 and three of layer 1 per hidden
@@ -213,6 +220,22 @@ __global__ __launch_bounds__(128) void psi_embed_event_kernel(const float* __res
     const float* l0v = l0 + (size_t)(v < V ? v : 0) * HD * 8;
     const float* w4v = w4t + (size_t)(v < V ? v : 0) * HD * E;
     const float* b4v = b4 + (size_t)(v < V ? v : 0) * E;
+    if (v == V) {
+        // the static column's row: this sample's tab_encoder output (Linear(Ds,Hd) -> ReLU -> BN affine -> Linear(Hd,E), model :57,
+        // duett.py:124-125) computed here, one hidden unit per thread — no separate launch in front of the psi build
+        for (int j = threadIdx.x; j < tw.Hd; j += 128) {
+            float a = tw.b0[j];
+            for (int i = 0; i < tw.Ds; ++i) a += tw.w0[j * tw.Ds + i] * tw.xs[(size_t)b * tw.Ds + i];
+            s_hid[j] = fmaxf(a, 0.f) * tw.s[j] + tw.sh[j];
+        }
+        __syncthreads();
+        if (threadIdx.x < E) {
+            float a = tw.b4[threadIdx.x];
+            for (int j = 0; j < tw.Hd; ++j) a += tw.w4[threadIdx.x * tw.Hd + j] * s_hid[j];
+            s_tab[threadIdx.x] = a;
+        }
+        __syncthreads();
+    }
     for (int t = threadIdx.x; t < T1; t += 128) {
         float out[E];
         const float* src = nullptr;
@@ -223,7 +246,7 @@ __global__ __launch_bounds__(128) void psi_embed_event_kernel(const float* __res
             if (row[2 * V] == 1.0f) {
                 src = special;                                   // masked timestep                         (model :61-64)
             } else if (v == V) {
-                src = tab_out + (size_t)b * E;                   // static column                           (model :57)
+                src = s_tab;                                     // static column                           (model :57)
             } else {
                 const float cnt = row[V + v];
                 if (cnt == -1.0f) {
@@ -436,11 +459,6 @@ extern "C" int medp_duett_encode(const MedpDuettWeights* w, const float* xs_stat
     float* temb = (float*)(base + ws.temb);
     float* rn = (float*)(base + ws.rn);
 
-    tab_encoder_kernel<<<B, 128, w->d_hidden_tab * sizeof(float), s>>>(xs_static, (const float*)w->tab_w0, (const float*)w->tab_b0,
-                                                                       (const float*)w->tab_bn_scale, (const float*)w->tab_bn_shift,
-                                                                       (const float*)w->tab_w4, (const float*)w->tab_b4, tab,
-                                                                       w->n_static, w->d_hidden_tab, E);
-    MEDP_LAUNCH_CHECK("duett tab_encoder");
     const int E4 = E / 4;
     MEDP_CHECK_ARG((size_t)B * T1 * V1 * E4 < (1ull << 31), "duett_encode: B*(T+1)*(V+1)*E/4 must stay below 2^31");
     MEDP_CHECK_ARG((size_t)T1 * E * 4 <= 100 * 1024, "duett_encode: a (T+1)*E row must fit the embed kernel's LDS tile");
@@ -450,12 +468,20 @@ extern "C" int medp_duett_encode(const MedpDuettWeights* w, const float* xs_stat
     const int swap_grid = grid_for((size_t)B * T1 * V1 * E4);
     if (fused) {
         MEDP_CHECK_ARG(w->emb_l0 && w->emb_w4t, "duett_encode: emb_l0 / emb_w4t (scalar-load weight layout) missing");
-        psi_embed_event_kernel<24, 64><<<dim3(V1, B), 128, (size_t)T1 * E * sizeof(float), s>>>(
-            xs_ts, (const float*)w->emb_l0, (const float*)w->emb_w4t, (const float*)w->emb_b4, (const float*)w->n_obs_table, w->n_obs_rows, tab,
+        MEDP_CHECK_ARG(w->d_hidden_tab <= 256, "duett_encode: tab encoder hidden size above 256");
+        const TabWeights tw{xs_static, (const float*)w->tab_w0, (const float*)w->tab_b0, (const float*)w->tab_bn_scale, (const float*)w->tab_bn_shift,
+                            (const float*)w->tab_w4, (const float*)w->tab_b4, w->n_static, w->d_hidden_tab};
+        psi_embed_event_kernel<24, 64><<<dim3(B, V1), 128, (size_t)T1 * E * sizeof(float), s>>>(
+            xs_ts, (const float*)w->emb_l0, (const float*)w->emb_w4t, (const float*)w->emb_b4, (const float*)w->n_obs_table, w->n_obs_rows, tw,
             (const float*)w->special, (const float*)w->event_embedding, (const float*)w->event_enc[0].g_attn, w->norm_eps, xe,
             (bf16_t*)(base + ws.h), psi0_out, B, T, V);
         MEDP_LAUNCH_CHECK("duett psi_embed_event");
     } else {
+        tab_encoder_kernel<<<B, 128, w->d_hidden_tab * sizeof(float), s>>>(xs_static, (const float*)w->tab_w0, (const float*)w->tab_b0,
+                                                                           (const float*)w->tab_bn_scale, (const float*)w->tab_bn_shift,
+                                                                           (const float*)w->tab_w4, (const float*)w->tab_b4, tab,
+                                                                           w->n_static, w->d_hidden_tab, E);
+        MEDP_LAUNCH_CHECK("duett tab_encoder");
         psi_embed_kernel<24, 64><<<dim3((B * T1 + 255) / 256, V1), 256, 0, s>>>(
             xs_ts, (const float*)w->emb_w0, (const float*)w->emb_b0, (const float*)w->emb_bn_scale, (const float*)w->emb_bn_shift,
             (const float*)w->emb_w4, (const float*)w->emb_b4, (const float*)w->n_obs_table, w->n_obs_rows, tab, (const float*)w->special, psi,
@@ -536,17 +562,17 @@ extern "C" int medp_duett_embed_fwd(const MedpDuettWeights* w, const float* xs_s
     hipStream_t s = (hipStream_t)stream;
     const int V = w->n_vars, V1 = V + 1, T1 = T + 1, E = w->d_embedding, tt = E * V1;
     if (stages & 1) {
-        MEDP_CHECK_ARG(xe_out && h_out && tab_workspace, "duett_embed_fwd: stage 1 needs xe_out, h_out and a B*E float workspace");
+        MEDP_CHECK_ARG(xe_out && h_out, "duett_embed_fwd: stage 1 needs xe_out and h_out");
+        (void)tab_workspace;          // kept in the signature; the static encoder runs inside the fused kernel
         MEDP_CHECK_ARG((size_t)T1 * E * 4 <= 100 * 1024, "duett_embed_fwd: a (T+1)*E row must fit the LDS tile");
-        tab_encoder_kernel<<<B, 128, w->d_hidden_tab * sizeof(float), s>>>(xs_static, (const float*)w->tab_w0, (const float*)w->tab_b0,
-                                                                           (const float*)w->tab_bn_scale, (const float*)w->tab_bn_shift,
-                                                                           (const float*)w->tab_w4, (const float*)w->tab_b4, tab_workspace,
-                                                                           w->n_static, w->d_hidden_tab, E);
         MEDP_CHECK_ARG(w->emb_l0 && w->emb_w4t, "duett_embed_fwd: emb_l0 / emb_w4t (scalar-load weight layout) missing");
-        psi_embed_event_kernel<24, 64><<<dim3(V1, B), 128, (size_t)T1 * E * sizeof(float), s>>>(
-            xs_ts, (const float*)w->emb_l0, (const float*)w->emb_w4t, (const float*)w->emb_b4, (const float*)w->n_obs_table, w->n_obs_rows,
-            tab_workspace, (const float*)w->special, (const float*)w->event_embedding, (const float*)w->event_enc[0].g_attn, w->norm_eps,
-            xe_out, (bf16_t*)h_out, psi0_out, B, T, V);
+        MEDP_CHECK_ARG(w->d_hidden_tab <= 256, "duett_embed_fwd: tab encoder hidden size above 256");
+        const TabWeights tw{xs_static, (const float*)w->tab_w0, (const float*)w->tab_b0, (const float*)w->tab_bn_scale, (const float*)w->tab_bn_shift,
+                            (const float*)w->tab_w4, (const float*)w->tab_b4, w->n_static, w->d_hidden_tab};
+        psi_embed_event_kernel<24, 64><<<dim3(B, V1), 128, (size_t)T1 * E * sizeof(float), s>>>(
+            xs_ts, (const float*)w->emb_l0, (const float*)w->emb_w4t, (const float*)w->emb_b4, (const float*)w->n_obs_table, w->n_obs_rows, tw,
+            (const float*)w->special, (const float*)w->event_embedding, (const float*)w->event_enc[0].g_attn, w->norm_eps, xe_out,
+            (bf16_t*)h_out, psi0_out, B, T, V);
         MEDP_LAUNCH_CHECK("duett_embed_fwd(psi)");
     }
     if (stages & 2) {

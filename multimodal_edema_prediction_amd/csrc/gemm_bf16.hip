@@ -645,7 +645,11 @@ int medp_gemm_bf16_nt_tagged_ws(int tag, const void* A, const void* W, void* C, 
     }
     static const int force = [] { const char* e = getenv("MEDP_GEMM_VARIANT"); return e ? atoi(e) : 0; }();   // 1 = v1, 2 = v2 (A/B tests)
     const bool use_v2 = force == 2;
-    const bool use_v3 = force == 3 || (force == 0 && M >= 2048 && N >= 256);
+    // v3 (256 x 128 tiles) only where its grid covers most of the chip: below that the 128 x 128 kernel has twice the tiles
+    // (img_proj: 130 -> 258, DuETT ff1 on the time axis: 100 -> 196) and wins on CU fill what it loses per tile
+    static const int v3_min_tiles = [] { const char* e = getenv("MEDP_GEMM_V3_MIN_TILES"); return e ? atoi(e) : 192; }();
+    const int tiles_v3 = ((M + 255) / 256) * ((N + 127) / 128);
+    const bool use_v3 = force == 3 || (force == 0 && M >= 2048 && N >= 256 && tiles_v3 >= v3_min_tiles);
     MedpGemmArgs a4{A, W, C, M, N, K, lda, ldw, ldc, bias, scale, residual, ldr, act, out_bf16, nullptr};
     if (N <= 64) return launch<128, 64, 0>(p, s);
     // v6 (256 x 256 x 64, 8 waves ping-pong, gemm_bf16_v6.hip) runs ONE workgroup per CU: default once there are enough
