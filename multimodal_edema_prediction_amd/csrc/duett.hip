@@ -198,6 +198,7 @@ struct TabWeights {
     const float *xs, *w0, *b0, *s, *sh, *w4, *b4;
     int Ds, Hd;
 };
+constexpr int PE_NB = 4;      // batch elements (event-view rows of one variable) per workgroup of the fused embed kernel
 template <int E, int HD>
 __global__ __launch_bounds__(128) void psi_embed_event_kernel(const float* __restrict__ xs_ts, const float* __restrict__ l0,
                                                               const float* __restrict__ w4t, const float* __restrict__ b4,
@@ -206,107 +207,150 @@ __global__ __launch_bounds__(128) void psi_embed_event_kernel(const float* __res
                                                               const float* __restrict__ event_emb, const float* __restrict__ g_norm,
                                                               float norm_eps, float* __restrict__ xe, bf16_t* __restrict__ h,
                                                               float* __restrict__ psi0_out, int B, int T, int V) {
-    extern __shared__ __attribute__((aligned(16))) float tile[];          // [(T+1)*E] the row
-    __shared__ float s_rn, s_tab[E], s_hid[256];
-    // grid (B, V+1): the batch index is the FAST block index, so the workgroups resident on a CU at any time share one or two
-    // variables — their weights (7.4 KB per variable) then stay in the 16-KB scalar cache; with the variable as the fast index
-    // every resident workgroup streamed a different variable's weights through it.
-    const int b = blockIdx.x, v = blockIdx.y;
+    // A workgroup = one variable v x PE_NB consecutive batch elements: the variable's MLP (7.5 KB) is staged in LDS ONCE for
+    // 4 x (T+1) cells, and every lane carries FOUR cells (one per batch element) through the hidden-unit loop, so one broadcast
+    // LDS read of a weight feeds four cells' FMAs.  (One cell per lane made the CU's single LDS pipe the bound — 11 reads per
+    // 16 VALU instructions, 50 us at cfg3; weights by scalar loads instead left the waves parked on SMEM latency: 79 % of the
+    // wave cycles in s_waitcnt, 48 us.)
+    extern __shared__ __attribute__((aligned(16))) float tile[];          // [PE_NB][(T+1)*E] the rows
+    __shared__ __attribute__((aligned(16))) float sl0[HD * 8], sw4[HD * E], sb4[E];
+    __shared__ float s_rn[PE_NB], s_tab[PE_NB][E], s_hid[256];
+    const int v = blockIdx.y, b0 = blockIdx.x * PE_NB;
+    const int nb = min(PE_NB, B - b0);
     const int T1 = T + 1, F = 2 * V + 1, D = T1 * E, D4 = D >> 2;
-    // The variable's MLP weights are the same for every lane of the workgroup: they are read straight from global memory at
-    // wave-uniform addresses, i.e. by SCALAR loads into SGPRs (one s_load_dwordx8 of layer 0 and three of layer 1 per hidden
-    // unit), and enter the FMAs as scalar operands.  The first form kept them in LDS: 11 LDS reads per hidden unit and lane
-    // made the one LDS pipe of the CU, shared by its four SIMDs, the bound (50 us at cfg3 against ~10 us of VALU work).
-    const float* l0v = l0 + (size_t)(v < V ? v : 0) * HD * 8;
-    const float* w4v = w4t + (size_t)(v < V ? v : 0) * HD * E;
-    const float* b4v = b4 + (size_t)(v < V ? v : 0) * E;
-    if (v == V) {
-        // the static column's row: this sample's tab_encoder output (Linear(Ds,Hd) -> ReLU -> BN affine -> Linear(Hd,E), model :57,
+    if (v < V) {
+        for (int i = threadIdx.x; i < HD * 8 / 4; i += 128) ((float4*)sl0)[i] = ((const float4*)(l0 + (size_t)v * HD * 8))[i];
+        for (int i = threadIdx.x; i < HD * E / 4; i += 128) ((float4*)sw4)[i] = ((const float4*)(w4t + (size_t)v * HD * E))[i];
+        if (threadIdx.x < E) sb4[threadIdx.x] = b4[(size_t)v * E + threadIdx.x];
+    } else {
+        // the static column's rows: each sample's tab_encoder output (Linear(Ds,Hd) -> ReLU -> BN affine -> Linear(Hd,E), model :57,
         // duett.py:124-125) computed here, one hidden unit per thread — no separate launch in front of the psi build
-        for (int j = threadIdx.x; j < tw.Hd; j += 128) {
-            float a = tw.b0[j];
-            for (int i = 0; i < tw.Ds; ++i) a += tw.w0[j * tw.Ds + i] * tw.xs[(size_t)b * tw.Ds + i];
-            s_hid[j] = fmaxf(a, 0.f) * tw.s[j] + tw.sh[j];
+        for (int bb = 0; bb < nb; ++bb) {
+            for (int j = threadIdx.x; j < tw.Hd; j += 128) {
+                float a = tw.b0[j];
+                for (int i = 0; i < tw.Ds; ++i) a += tw.w0[j * tw.Ds + i] * tw.xs[(size_t)(b0 + bb) * tw.Ds + i];
+                s_hid[j] = fmaxf(a, 0.f) * tw.s[j] + tw.sh[j];
+            }
+            __syncthreads();
+            if (threadIdx.x < E) {
+                float a = tw.b4[threadIdx.x];
+                for (int j = 0; j < tw.Hd; ++j) a += tw.w4[threadIdx.x * tw.Hd + j] * s_hid[j];
+                s_tab[bb][threadIdx.x] = a;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        if (threadIdx.x < E) {
-            float a = tw.b4[threadIdx.x];
-            for (int j = 0; j < tw.Hd; ++j) a += tw.w4[threadIdx.x * tw.Hd + j] * s_hid[j];
-            s_tab[threadIdx.x] = a;
-        }
-        __syncthreads();
     }
+    __syncthreads();
     for (int t = threadIdx.x; t < T1; t += 128) {
-        float out[E];
-        const float* src = nullptr;
-        if (t == T) {
-            src = special + E;                                   // REP row                                 (model :58-60)
-        } else {
-            const float* row = xs_ts + ((size_t)b * T + t) * F;
-            if (row[2 * V] == 1.0f) {
-                src = special;                                   // masked timestep                         (model :61-64)
-            } else if (v == V) {
-                src = s_tab;                                     // static column                           (model :57)
+        float out[PE_NB][E];
+        float val[PE_NB], nob[PE_NB];
+        const float* src[PE_NB];
+        bool any_mlp = false;
+#pragma unroll
+        for (int bb = 0; bb < PE_NB; ++bb) {
+            src[bb] = nullptr;
+            val[bb] = nob[bb] = 0.f;
+            if (bb >= nb) { src[bb] = special; continue; }             // no such row: computed on zeros, never stored
+            if (t == T) {
+                src[bb] = special + E;                                   // REP row                                 (model :58-60)
             } else {
-                const float cnt = row[V + v];
-                if (cnt == -1.0f) {
-                    src = special;                               // masked event (SSL only)                 (model :65-66)
+                const float* row = xs_ts + ((size_t)(b0 + bb) * T + t) * F;
+                if (row[2 * V] == 1.0f) {
+                    src[bb] = special;                                   // masked timestep                         (model :61-64)
+                } else if (v == V) {
+                    src[bb] = s_tab[bb];                                 // static column                           (model :57)
                 } else {
-                    const int idx = min(max((int)cnt, 0), nobs_rows - 1);
-                    const float val = row[v], nob = nobs_table[idx];
-#pragma unroll
-                    for (int e = 0; e < E; ++e) out[e] = b4v[e];
-#pragma unroll 4
-                    for (int j = 0; j < HD; ++j) {
-                        const float* lj = l0v + j * 8;
-                        const float hj = fmaxf(lj[0] * val + lj[1] * nob + lj[2], 0.f) * lj[3] + lj[4];
-                        const float* wj = w4v + j * E;
-#pragma unroll
-                        for (int e = 0; e < E; ++e) out[e] += wj[e] * hj;
+                    const float cnt = row[V + v];
+                    if (cnt == -1.0f) {
+                        src[bb] = special;                               // masked event (SSL only)                 (model :65-66)
+                    } else {
+                        val[bb] = row[v];
+                        nob[bb] = nobs_table[min(max((int)cnt, 0), nobs_rows - 1)];    // .to(int).clip(0, 15) (model :41)
+                        any_mlp = true;
                     }
                 }
             }
         }
-        if (src) {
+        if (v < V && __any(any_mlp)) {
 #pragma unroll
-            for (int e = 0; e < E; ++e) out[e] = src[e];
+            for (int bb = 0; bb < PE_NB; ++bb)
+#pragma unroll
+                for (int e = 0; e < E; ++e) out[bb][e] = sb4[e];
+#pragma unroll 2
+            for (int j = 0; j < HD; ++j) {
+                const float4 la = *(const float4*)(sl0 + j * 8);        // w0[j][0], w0[j][1], b0[j], bn scale
+                const float lsh = sl0[j * 8 + 4];                        // bn shift
+                float hj[PE_NB];
+#pragma unroll
+                for (int bb = 0; bb < PE_NB; ++bb) hj[bb] = fmaxf(la.x * val[bb] + la.y * nob[bb] + la.z, 0.f) * la.w + lsh;
+                const float4* wj = (const float4*)(sw4 + j * E);
+#pragma unroll
+                for (int e4 = 0; e4 < E / 4; ++e4) {
+                    const float4 w = wj[e4];
+#pragma unroll
+                    for (int bb = 0; bb < PE_NB; ++bb) {
+                        out[bb][4 * e4] += w.x * hj[bb]; out[bb][4 * e4 + 1] += w.y * hj[bb];
+                        out[bb][4 * e4 + 2] += w.z * hj[bb]; out[bb][4 * e4 + 3] += w.w * hj[bb];
+                    }
+                }
+            }
         }
-        if (psi0_out) {                                          // parity checks only: psi0 in the time view, before the add
-            float* d0 = psi0_out + (((size_t)b * T1 + t) * (V + 1) + v) * E;
 #pragma unroll
-            for (int e = 0; e < E; e += 4) *(float4*)(d0 + e) = make_float4(out[e], out[e + 1], out[e + 2], out[e + 3]);
+        for (int bb = 0; bb < PE_NB; ++bb) {
+            if (bb >= nb) continue;
+            if (src[bb]) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) out[bb][e] = src[bb][e];
+            }
+            if (psi0_out) {                                          // parity checks only: psi0 in the time view, before the add
+                float* d0 = psi0_out + (((size_t)(b0 + bb) * T1 + t) * (V + 1) + v) * E;
+#pragma unroll
+                for (int e = 0; e < E; e += 4) *(float4*)(d0 + e) = make_float4(out[bb][e], out[bb][e + 1], out[bb][e + 2], out[bb][e + 3]);
+            }
+#pragma unroll
+            for (int e = 0; e < E; e += 4)
+                *(float4*)(tile + (size_t)bb * D + t * E + e) = make_float4(out[bb][e], out[bb][e + 1], out[bb][e + 2], out[bb][e + 3]);
         }
-#pragma unroll
-        for (int e = 0; e < E; ++e) tile[t * E + e] = out[e];
     }
     __syncthreads();
-    // + event embedding (row v of [V+1, (T+1)E]) ; fp32 row out, coalesced
-    const size_t rbase = ((size_t)b * (V + 1) + v) * D;
-    for (int i = threadIdx.x; i < D4; i += 128) {
-        float4 x = *(float4*)(tile + 4 * i);
-        const float4 a = *(const float4*)(event_emb + (size_t)v * D + 4 * i);
-        x = make_float4(x.x + a.x, x.y + a.y, x.z + a.z, x.w + a.w);
-        *(float4*)(tile + 4 * i) = x;
-        *(float4*)(xe + rbase + 4 * i) = x;
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {                                      // canonical order: lane + 64 k, then the wave tree
-        float ss = 0.f;
-        for (int i = threadIdx.x; i < D4; i += 64) {
-            const float4 x = *(const float4*)(tile + 4 * i);
-            ss += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+    // + event embedding (row v of [V+1, (T+1)E]) ; fp32 rows out, coalesced
+    for (int bb = 0; bb < nb; ++bb) {
+        const size_t rbase = ((size_t)(b0 + bb) * (V + 1) + v) * D;
+        float* tb = tile + (size_t)bb * D;
+        for (int i = threadIdx.x; i < D4; i += 128) {
+            float4 x = *(float4*)(tb + 4 * i);
+            const float4 a = *(const float4*)(event_emb + (size_t)v * D + 4 * i);
+            x = make_float4(x.x + a.x, x.y + a.y, x.z + a.z, x.w + a.w);
+            *(float4*)(tb + 4 * i) = x;
+            *(float4*)(xe + rbase + 4 * i) = x;
         }
-        const float rn = 1.0f / fmaxf(sqrtf(wave_sum(ss)), norm_eps);
-        if (threadIdx.x == 0) s_rn = rn;
     }
     __syncthreads();
-    const float sc = s_rn * sqrtf((float)D) * g_norm[0];
-    for (int i = threadIdx.x; i < D4; i += 128) {
-        const float4 x = *(const float4*)(tile + 4 * i);
-        uint2 o;
-        o.x = pack_bf2(x.x * sc, x.y * sc);
-        o.y = pack_bf2(x.z * sc, x.w * sc);
-        *(uint2*)(h + rbase + 4 * i) = o;
+    {   // row norms: wave w takes rows w, w+2 in the canonical order (lane + 64 k, then the wave tree) of scalenorm_fwd_reg_kernel
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int bb = wave; bb < nb; bb += 2) {
+            const float* tb = tile + (size_t)bb * D;
+            float ss = 0.f;
+            for (int i = lane; i < D4; i += 64) {
+                const float4 x = *(const float4*)(tb + 4 * i);
+                ss += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+            }
+            const float rn = 1.0f / fmaxf(sqrtf(wave_sum(ss)), norm_eps);
+            if (lane == 0) s_rn[bb] = rn;
+        }
+    }
+    __syncthreads();
+    for (int bb = 0; bb < nb; ++bb) {
+        const size_t rbase = ((size_t)(b0 + bb) * (V + 1) + v) * D;
+        const float* tb = tile + (size_t)bb * D;
+        const float sc = s_rn[bb] * sqrtf((float)D) * g_norm[0];
+        for (int i = threadIdx.x; i < D4; i += 128) {
+            const float4 x = *(const float4*)(tb + 4 * i);
+            uint2 o;
+            o.x = pack_bf2(x.x * sc, x.y * sc);
+            o.y = pack_bf2(x.z * sc, x.w * sc);
+            *(uint2*)(h + rbase + 4 * i) = o;
+        }
     }
 }
 
@@ -369,6 +413,26 @@ int launch_swap_add_norm(const float* in, const float* rnorm, const float* g_pre
     else return 1;          // wider rows: the caller takes the two-launch path
 #undef MEDP_SAN
     MEDP_LAUNCH_CHECK("duett swap+add+norm");
+    return 0;
+}
+
+int launch_psi_embed_event(const MedpDuettWeights* w, const float* xs_static, const float* xs_ts, float* xe, void* h, float* psi0_out, int B,
+                           int T, hipStream_t s) {
+    const int V = w->n_vars, V1 = V + 1, T1 = T + 1, E = w->d_embedding;
+    MEDP_CHECK_ARG(w->emb_l0 && w->emb_w4t, "duett: emb_l0 / emb_w4t (transposed weight layout) missing");
+    MEDP_CHECK_ARG(w->d_hidden_tab <= 256, "duett: tab encoder hidden size above 256");
+    const size_t lds = (size_t)PE_NB * T1 * E * sizeof(float);
+    MEDP_CHECK_ARG(lds <= 120 * 1024, "duett: 4 rows of (T+1)*E floats must fit the embed kernel's LDS tile");
+    MEDP_ONCE_PER_DEVICE({
+        (void)hipFuncSetAttribute((const void*)psi_embed_event_kernel<24, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    });
+    const TabWeights tw{xs_static, (const float*)w->tab_w0, (const float*)w->tab_b0, (const float*)w->tab_bn_scale, (const float*)w->tab_bn_shift,
+                        (const float*)w->tab_w4, (const float*)w->tab_b4, w->n_static, w->d_hidden_tab};
+    psi_embed_event_kernel<24, 64><<<dim3((B + PE_NB - 1) / PE_NB, V1), 128, lds, s>>>(
+        xs_ts, (const float*)w->emb_l0, (const float*)w->emb_w4t, (const float*)w->emb_b4, (const float*)w->n_obs_table, w->n_obs_rows, tw,
+        (const float*)w->special, (const float*)w->event_embedding, (const float*)w->event_enc[0].g_attn, w->norm_eps, xe, (bf16_t*)h, psi0_out,
+        B, T, V);
+    MEDP_LAUNCH_CHECK("duett psi_embed_event");
     return 0;
 }
 
@@ -461,21 +525,12 @@ extern "C" int medp_duett_encode(const MedpDuettWeights* w, const float* xs_stat
 
     const int E4 = E / 4;
     MEDP_CHECK_ARG((size_t)B * T1 * V1 * E4 < (1ull << 31), "duett_encode: B*(T+1)*(V+1)*E/4 must stay below 2^31");
-    MEDP_CHECK_ARG((size_t)T1 * E * 4 <= 100 * 1024, "duett_encode: a (T+1)*E row must fit the embed kernel's LDS tile");
     // Layer 0, event view, in ONE launch: psi build + axis swap + event embedding + the event encoder's first ScaleNorm.
     // MEDP_DUETT_FUSED=0 keeps the separate launches (psi_embed -> swap -> scalenorm ...) for A/B runs; same values.
     static const bool fused = [] { const char* e = getenv("MEDP_DUETT_FUSED"); return !e || atoi(e) != 0; }();
     const int swap_grid = grid_for((size_t)B * T1 * V1 * E4);
     if (fused) {
-        MEDP_CHECK_ARG(w->emb_l0 && w->emb_w4t, "duett_encode: emb_l0 / emb_w4t (scalar-load weight layout) missing");
-        MEDP_CHECK_ARG(w->d_hidden_tab <= 256, "duett_encode: tab encoder hidden size above 256");
-        const TabWeights tw{xs_static, (const float*)w->tab_w0, (const float*)w->tab_b0, (const float*)w->tab_bn_scale, (const float*)w->tab_bn_shift,
-                            (const float*)w->tab_w4, (const float*)w->tab_b4, w->n_static, w->d_hidden_tab};
-        psi_embed_event_kernel<24, 64><<<dim3(B, V1), 128, (size_t)T1 * E * sizeof(float), s>>>(
-            xs_ts, (const float*)w->emb_l0, (const float*)w->emb_w4t, (const float*)w->emb_b4, (const float*)w->n_obs_table, w->n_obs_rows, tw,
-            (const float*)w->special, (const float*)w->event_embedding, (const float*)w->event_enc[0].g_attn, w->norm_eps, xe,
-            (bf16_t*)(base + ws.h), psi0_out, B, T, V);
-        MEDP_LAUNCH_CHECK("duett psi_embed_event");
+        MEDP_TRY(launch_psi_embed_event(w, xs_static, xs_ts, xe, base + ws.h, psi0_out, B, T, s));
     } else {
         tab_encoder_kernel<<<B, 128, w->d_hidden_tab * sizeof(float), s>>>(xs_static, (const float*)w->tab_w0, (const float*)w->tab_b0,
                                                                            (const float*)w->tab_bn_scale, (const float*)w->tab_bn_shift,
@@ -564,16 +619,7 @@ extern "C" int medp_duett_embed_fwd(const MedpDuettWeights* w, const float* xs_s
     if (stages & 1) {
         MEDP_CHECK_ARG(xe_out && h_out, "duett_embed_fwd: stage 1 needs xe_out and h_out");
         (void)tab_workspace;          // kept in the signature; the static encoder runs inside the fused kernel
-        MEDP_CHECK_ARG((size_t)T1 * E * 4 <= 100 * 1024, "duett_embed_fwd: a (T+1)*E row must fit the LDS tile");
-        MEDP_CHECK_ARG(w->emb_l0 && w->emb_w4t, "duett_embed_fwd: emb_l0 / emb_w4t (scalar-load weight layout) missing");
-        MEDP_CHECK_ARG(w->d_hidden_tab <= 256, "duett_embed_fwd: tab encoder hidden size above 256");
-        const TabWeights tw{xs_static, (const float*)w->tab_w0, (const float*)w->tab_b0, (const float*)w->tab_bn_scale, (const float*)w->tab_bn_shift,
-                            (const float*)w->tab_w4, (const float*)w->tab_b4, w->n_static, w->d_hidden_tab};
-        psi_embed_event_kernel<24, 64><<<dim3(B, V1), 128, (size_t)T1 * E * sizeof(float), s>>>(
-            xs_ts, (const float*)w->emb_l0, (const float*)w->emb_w4t, (const float*)w->emb_b4, (const float*)w->n_obs_table, w->n_obs_rows, tw,
-            (const float*)w->special, (const float*)w->event_embedding, (const float*)w->event_enc[0].g_attn, w->norm_eps, xe_out,
-            (bf16_t*)h_out, psi0_out, B, T, V);
-        MEDP_LAUNCH_CHECK("duett_embed_fwd(psi)");
+        MEDP_TRY(launch_psi_embed_event(w, xs_static, xs_ts, xe_out, h_out, psi0_out, B, T, s));
     }
     if (stages & 2) {
         MEDP_CHECK_ARG(temb_out, "duett_embed_fwd: stage 2 needs temb_out");
