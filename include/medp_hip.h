@@ -50,6 +50,13 @@ int medp_gemm_bf16_nt_ws(const void* A, const void* W, void* C, int M, int N, in
                          const float* scale, const float* residual, int ldr, int act, int out_bf16, float* workspace,
                          size_t workspace_bytes, void* stream);
 
+/* FP32 KERNEL MODE (SURVEY.md 7 "always keep an fp32 kernel mode for tight checks"; 8(d) fp32 tolerances): the same two GEMMs with
+ * fp32 operands and fp32 FMA accumulation on the vector ALUs (no matrix cores): a parity instrument, selected explicitly by the
+ * host layer (functional.set_precision("fp32")), never by tensor dtype.  No alignment requirements. */
+int medp_gemm_f32_nt(const float* A, const float* W, float* C, int M, int N, int K, int lda, int ldw, int ldc, const float* bias,
+                     const float* scale, const float* residual, int ldr, int act, void* stream);
+int medp_gemm_f32_tn(const float* dY, const float* X, float* C, int M, int N, int K, int lddy, int ldx, void* stream);
+
 /* Weight gradient C[N,K] = sum_m dY[m,n] X[m,k] (fp32 out, bf16 row-major operands, transposing LDS reads, split over m with
  * a deterministic slab reduction): the dW of every trainable Linear (autograd of model :566,:749-757,:1027, duett.py:95-105). */
 size_t medp_gemm_tn_workspace_bytes(int M, int N, int K);

@@ -57,6 +57,8 @@ SIGNATURES = {
     "medp_gemm_bf16_nt": (I, [P, P, P, I, I, I, I, I, I, P, P, P, I, I, I, P]),
     "medp_gemm_nt_workspace_bytes": (SZ, [I, I, I]),
     "medp_gemm_bf16_nt_ws": (I, [P, P, P, I, I, I, I, I, I, P, P, P, I, I, I, P, SZ, P]),
+    "medp_gemm_f32_nt": (I, [P, P, P, I, I, I, I, I, I, P, P, P, I, I, P]),
+    "medp_gemm_f32_tn": (I, [P, P, P, I, I, I, I, I, P]),
     "medp_gemm_tn_workspace_bytes": (SZ, [I, I, I]),
     "medp_gemm_bf16_tn": (I, [P, P, P, I, I, I, I, I, P, P]),
     "medp_gemm_profile_enable": (I, [I]),

@@ -37,11 +37,16 @@ def _cached(t: torch.Tensor, kind: str, make):
 
 
 def weight_bf16(w: torch.Tensor) -> torch.Tensor:
+    """The weight as a GEMM operand: a cached bf16 copy; in fp32 mode (functional.set_precision) the fp32 weight itself."""
+    if Fn.precision() == "fp32":
+        return w.detach().contiguous()
     return _cached(w, "bf16", lambda t: Fn.to_bf16(t.contiguous()) if t.shape[-1] % 4 == 0 else t.to(BF16))
 
 
 def weight_t_bf16(w: torch.Tensor) -> torch.Tensor:
     """[N,K] fp32 -> [K, Npad8] bf16 (operand of dX = dY · W)."""
+    if Fn.precision() == "fp32":
+        return _cached(w, "t_f32", lambda t: Fn.transpose_to_bf16(t.contiguous()))
     return _cached(w, "t_bf16", lambda t: Fn.transpose_to_bf16(t.contiguous()))
 
 
@@ -59,12 +64,16 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual):
+        fp32 = Fn.precision() == "fp32"
+        if fp32 and x.dtype == BF16:
+            x = x.float()                                     # bf16 tokens of a frozen bf16 encoder entering an fp32-mode head
         xb = x if x.dtype == BF16 else Fn.to_bf16(x.contiguous())
         x2 = xb.reshape(-1, xb.shape[-1])
         N = weight.shape[0]
         if N % 4:                                             # e.g. the 7-label linear probe: pad the weight rows, slice the result
             Np = (N + 3) // 4 * 4
-            wpad = _cached(weight, "bf16_rowpad", lambda t: Fn.to_bf16(torch.cat([t, t.new_zeros(Np - N, t.shape[1])]).contiguous()))
+            wpad = _cached(weight, "f32_rowpad" if fp32 else "bf16_rowpad",
+                           lambda t: Fn.to_bf16(torch.cat([t, t.new_zeros(Np - N, t.shape[1])]).contiguous()))
             bpad = torch.cat([bias.detach(), bias.new_zeros(Np - N)]) if bias is not None else None
             y = Fn.gemm(x2, wpad, bias=bpad, out_dtype=F32, k=weight.shape[1])[:, :N].contiguous()
             if residual is not None:
@@ -94,7 +103,8 @@ class LinearFn(torch.autograd.Function):
             dyp = torch.zeros((dy2.shape[0], Np), dtype=F32, device=dy2.device)
             dyp[:, :N] = dy2
             if ctx.needs_input_grad[0]:
-                wt = _cached(weight, "t_bf16_colpad", lambda t: Fn.transpose_to_bf16(torch.cat([t, t.new_zeros(Np - N, K)]).contiguous()))
+                wt = _cached(weight, "t_f32_colpad" if Fn.precision() == "fp32" else "t_bf16_colpad",
+                             lambda t: Fn.transpose_to_bf16(torch.cat([t, t.new_zeros(Np - N, K)]).contiguous()))
                 dx = Fn.gemm(Fn.to_bf16(dyp), wt, out_dtype=F32, k=Np).view(ctx.x_shape)
             if ctx.needs_input_grad[1]:
                 dw = Fn.gemm(Fn.transpose_to_bf16(dyp), Fn.transpose_to_bf16(x2), out_dtype=F32)[:N].contiguous()
@@ -102,7 +112,7 @@ class LinearFn(torch.autograd.Function):
                 db = Fn.colsum(dy2)
             return dx, dw, db, None
         if ctx.needs_input_grad[0] or (ctx.needs_input_grad[1] and N % 8 == 0 and K % 8 == 0):
-            dyb = Fn.to_bf16(dy2) if N % 4 == 0 else dy2.to(BF16)
+            dyb = Fn.to_bf16(dy2) if (N % 4 == 0 or Fn.precision() == "fp32") else dy2.to(BF16)
         if ctx.needs_input_grad[0]:
             wt = weight_t_bf16(weight)                           # [K, Npad]
             dx = Fn.gemm(dyb, wt, out_dtype=F32, k=N).view(ctx.x_shape)

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(128) void psi_embed_event_kernel(const float* __res
     // wave cycles in s_waitcnt, 48 us.)
     extern __shared__ __attribute__((aligned(16))) float tile[];          // [PE_NB][(T+1)*E] the rows
     __shared__ __attribute__((aligned(16))) float sl0[HD * 8], sw4[HD * E], sb4[E];
-    __shared__ float s_rn[PE_NB], s_tab[PE_NB][E], s_hid[256];
+    __shared__ float s_rn[PE_NB], s_tab[PE_NB][E], s_hid[256], s_part[2][E];
     const int v = blockIdx.y, b0 = blockIdx.x * PE_NB;
     const int nb = min(PE_NB, B - b0);
     const int T1 = T + 1, F = 2 * V + 1, D = T1 * E, D4 = D >> 2;
@@ -232,11 +232,16 @@ __global__ __launch_bounds__(128) void psi_embed_event_kernel(const float* __res
                 s_hid[j] = fmaxf(a, 0.f) * tw.s[j] + tw.sh[j];
             }
             __syncthreads();
-            if (threadIdx.x < E) {
-                float a = tw.b4[threadIdx.x];
-                for (int j = 0; j < tw.Hd; ++j) a += tw.w4[threadIdx.x * tw.Hd + j] * s_hid[j];
-                s_tab[bb][threadIdx.x] = a;
+            // second Linear: lane j multiplies hidden unit j (coalesced weight reads), wave tree + the two waves' halves per output
+            // (a thread per output walked its 128 weights 512 B apart: 12 us per sample, the long pole of the whole launch)
+            for (int e = 0; e < E; ++e) {
+                float pa = 0.f;
+                for (int j = threadIdx.x; j < tw.Hd; j += 128) pa += tw.w4[e * tw.Hd + j] * s_hid[j];
+                pa = wave_sum(pa);
+                if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6][e] = pa;
             }
+            __syncthreads();
+            if (threadIdx.x < E) s_tab[bb][threadIdx.x] = tw.b4[threadIdx.x] + s_part[0][threadIdx.x] + s_part[1][threadIdx.x];
             __syncthreads();
         }
     }

@@ -416,8 +416,8 @@ class DuettFeatureExtractor(Model):
 
     def encode(self, x):
         """[B, T+1, 24*(V+1)] contextual tokens (model file :31-94)."""
-        if self.needs_training_path() or (self.training and any(p.requires_grad for p in self.parameters())):
-            from .duett_train import encode_training
+        if self.needs_training_path() or (self.training and any(p.requires_grad for p in self.parameters())) or Fn.precision() == "fp32":
+            from .duett_train import encode_training          # op-level form (also the only fp32-mode form, functional.set_precision)
             return encode_training(self, x)
         if self.training and self.transformer_dropout > 0:
             raise NotImplementedError("dropout inside a frozen DuETT in train() mode: the reference's step functions put frozen "

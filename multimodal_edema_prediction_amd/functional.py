@@ -2,6 +2,8 @@
 pointers + the current HIP stream, map return codes to exceptions.  No arithmetic happens in Python."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import abi
@@ -9,6 +11,38 @@ from .abi import check, lib, ptr, stream
 
 BF16 = torch.bfloat16
 F32 = torch.float32
+
+# ---- kernel precision mode ------------------------------------------------------------------------------------------------
+# "bf16" (default): GEMM operands are bf16 (MFMA), accumulation / norms / softmax / losses fp32 — the mode every throughput figure
+# is measured in.  "fp32": the op-level (trainable / autograd) paths keep fp32 operands end to end and run medp_gemm_f32_* — the
+# tight-parity instrument of SURVEY.md §7 / §8(d) (logits 1e-4, loss 1e-5, gradients element-wise).  The switch is explicit
+# (set_precision / the precision_mode context / MEDP_PRECISION), never inferred from tensor dtypes (§8b).  The whole-module C
+# calls of the FROZEN encoders (medp_vit_forward, medp_duett_encode) are bf16 by construction; in fp32 mode the DuETT backbone
+# runs its op-level form instead, the CXR encoder has no fp32 form.
+_PRECISION = os.environ.get("MEDP_PRECISION", "bf16")
+
+
+def precision() -> str:
+    return _PRECISION
+
+
+def set_precision(p: str) -> None:
+    global _PRECISION
+    if p not in ("bf16", "fp32"):
+        raise ValueError(f"precision must be 'bf16' or 'fp32', got {p!r}")
+    _PRECISION = p
+
+
+class precision_mode:
+    def __init__(self, p):
+        self.p = p
+
+    def __enter__(self):
+        self.prev = precision()
+        set_precision(self.p)
+
+    def __exit__(self, *a):
+        set_precision(self.prev)
 
 
 def _2d(t: torch.Tensor) -> torch.Tensor:
@@ -21,7 +55,9 @@ def _ld(t: torch.Tensor) -> int:
 
 
 def to_bf16(x: torch.Tensor) -> torch.Tensor:
-    """fp32 [.., C] -> bf16 (HIP cast kernel)."""
+    """fp32 [.., C] -> the GEMM operand type: bf16 (HIP cast kernel); in fp32 mode the tensor itself."""
+    if _PRECISION == "fp32":
+        return x.contiguous()
     x2 = _2d(x)
     y = torch.empty(x2.shape, dtype=BF16, device=x.device)
     check(lib().medp_cast_f32_bf16(ptr(x2), _ld(x2), ptr(y), y.stride(0), x2.shape[0], x2.shape[1], stream()), "cast")
@@ -33,6 +69,10 @@ def transpose_to_bf16(x: torch.Tensor) -> torch.Tensor:
     x2 = _2d(x)
     R, C = x2.shape
     Rp = (R + 7) // 8 * 8
+    if _PRECISION == "fp32":                      # layout plumbing only (the fp32 GEMM has no alignment needs; same padded shape)
+        y = torch.zeros((C, Rp), dtype=F32, device=x.device)
+        y[:, :R] = x2.to(F32).t()
+        return y
     y = torch.zeros((C, Rp), dtype=BF16, device=x.device) if Rp != R else torch.empty((C, Rp), dtype=BF16, device=x.device)
     check(lib().medp_transpose_to_bf16(ptr(x2), int(x2.dtype == BF16), _ld(x2), ptr(y), Rp, R, C, stream()), "transpose")
     return y
@@ -40,7 +80,18 @@ def transpose_to_bf16(x: torch.Tensor) -> torch.Tensor:
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, scale=None, residual=None, act: int = 0,
          out_dtype=F32, out: torch.Tensor | None = None, k: int | None = None) -> torch.Tensor:
-    """out[M,N] = epi(a[M,K] @ w[N,K]^T); a, w bf16 row-major (leading dims may exceed K)."""
+    """out[M,N] = epi(a[M,K] @ w[N,K]^T); a, w bf16 row-major (leading dims may exceed K); fp32 operands (fp32 mode): medp_gemm_f32_nt."""
+    if a.dtype == F32 and w.dtype == F32:
+        a2, w2 = _2d(a), _2d(w)
+        M, N = a2.shape[0], w2.shape[0]
+        K = k if k is not None else min(a2.shape[1], w2.shape[1])
+        if out is None:
+            out = torch.empty((M, N), dtype=F32, device=a.device)
+        assert out.dtype == F32, "fp32 mode produces fp32 results"
+        r2 = _2d(residual) if residual is not None else None
+        check(lib().medp_gemm_f32_nt(ptr(a2), ptr(w2), ptr(out), M, N, K, _ld(a2), _ld(w2), _ld(out), ptr(bias), ptr(scale), ptr(r2),
+                                     _ld(r2) if r2 is not None else 0, act, stream()), "gemm_f32")
+        return out
     assert a.dtype == BF16 and w.dtype == BF16
     a2, w2 = _2d(a), _2d(w)
     M, N = a2.shape[0], w2.shape[0]
@@ -58,7 +109,6 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias=None, scale=None, residual=None,
 def gemm_tn(dy: torch.Tensor, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
     """dW[N,K] = dy[M,N]^T @ x[M,K] (bf16 row-major operands, fp32 result) — the weight gradient of a Linear.
     `out`: optional contiguous [N, K] fp32 destination (e.g. a row block of a larger gradient)."""
-    assert dy.dtype == BF16 and x.dtype == BF16
     dy2, x2 = _2d(dy), _2d(x)
     M, N = dy2.shape
     K = x2.shape[1]
@@ -66,6 +116,10 @@ def gemm_tn(dy: torch.Tensor, x: torch.Tensor, out: torch.Tensor | None = None) 
     if out is None:
         out = torch.empty((N, K), dtype=F32, device=dy.device)
     assert out.shape == (N, K) and out.dtype == F32 and out.is_contiguous()
+    if dy.dtype == F32 and x.dtype == F32:
+        check(lib().medp_gemm_f32_tn(ptr(dy2), ptr(x2), ptr(out), M, N, K, _ld(dy2), _ld(x2), stream()), "gemm_f32_tn")
+        return out
+    assert dy.dtype == BF16 and x.dtype == BF16
     wsb = lib().medp_gemm_tn_workspace_bytes(M, N, K)
     ws = torch.empty(wsb // 4, dtype=F32, device=dy.device) if wsb else None
     check(lib().medp_gemm_bf16_tn(ptr(dy2), ptr(x2), ptr(out), M, N, K, _ld(dy2), _ld(x2), ptr(ws), stream()), "gemm_tn")
