@@ -40,14 +40,14 @@ def weight_bf16(w: torch.Tensor) -> torch.Tensor:
     """The weight as a GEMM operand: a cached bf16 copy; in fp32 mode (functional.set_precision) the fp32 weight itself."""
     if Fn.precision() == "fp32":
         return w.detach().contiguous()
-    return _cached(w, "bf16", lambda t: Fn.to_bf16(t.contiguous()) if t.shape[-1] % 4 == 0 else t.to(BF16))
+    return _cached(w, "bf16", lambda t: Fn.operand(t.contiguous()) if t.shape[-1] % 4 == 0 else t.to(BF16))
 
 
 def weight_t_bf16(w: torch.Tensor) -> torch.Tensor:
     """[N,K] fp32 -> [K, Npad8] bf16 (operand of dX = dY · W)."""
     if Fn.precision() == "fp32":
-        return _cached(w, "t_f32", lambda t: Fn.transpose_to_bf16(t.contiguous()))
-    return _cached(w, "t_bf16", lambda t: Fn.transpose_to_bf16(t.contiguous()))
+        return _cached(w, "t_f32", lambda t: Fn.operand_t(t.contiguous()))
+    return _cached(w, "t_bf16", lambda t: Fn.operand_t(t.contiguous()))
 
 
 _SEED_STATE = {"n": 0}
@@ -67,13 +67,13 @@ class LinearFn(torch.autograd.Function):
         fp32 = Fn.precision() == "fp32"
         if fp32 and x.dtype == BF16:
             x = x.float()                                     # bf16 tokens of a frozen bf16 encoder entering an fp32-mode head
-        xb = x if x.dtype == BF16 else Fn.to_bf16(x.contiguous())
+        xb = x if x.dtype == BF16 else Fn.operand(x.contiguous())
         x2 = xb.reshape(-1, xb.shape[-1])
         N = weight.shape[0]
         if N % 4:                                             # e.g. the 7-label linear probe: pad the weight rows, slice the result
             Np = (N + 3) // 4 * 4
             wpad = _cached(weight, "f32_rowpad" if fp32 else "bf16_rowpad",
-                           lambda t: Fn.to_bf16(torch.cat([t, t.new_zeros(Np - N, t.shape[1])]).contiguous()))
+                           lambda t: Fn.operand(torch.cat([t, t.new_zeros(Np - N, t.shape[1])]).contiguous()))
             bpad = torch.cat([bias.detach(), bias.new_zeros(Np - N)]) if bias is not None else None
             y = Fn.gemm(x2, wpad, bias=bpad, out_dtype=F32, k=weight.shape[1])[:, :N].contiguous()
             if residual is not None:
@@ -104,15 +104,15 @@ class LinearFn(torch.autograd.Function):
             dyp[:, :N] = dy2
             if ctx.needs_input_grad[0]:
                 wt = _cached(weight, "t_f32_colpad" if Fn.precision() == "fp32" else "t_bf16_colpad",
-                             lambda t: Fn.transpose_to_bf16(torch.cat([t, t.new_zeros(Np - N, K)]).contiguous()))
-                dx = Fn.gemm(Fn.to_bf16(dyp), wt, out_dtype=F32, k=Np).view(ctx.x_shape)
+                             lambda t: Fn.operand_t(torch.cat([t, t.new_zeros(Np - N, K)]).contiguous()))
+                dx = Fn.gemm(Fn.operand(dyp), wt, out_dtype=F32, k=Np).view(ctx.x_shape)
             if ctx.needs_input_grad[1]:
-                dw = Fn.gemm(Fn.transpose_to_bf16(dyp), Fn.transpose_to_bf16(x2), out_dtype=F32)[:N].contiguous()
+                dw = Fn.gemm(Fn.operand_t(dyp), Fn.operand_t(x2), out_dtype=F32)[:N].contiguous()
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = Fn.colsum(dy2)
             return dx, dw, db, None
         if ctx.needs_input_grad[0] or (ctx.needs_input_grad[1] and N % 8 == 0 and K % 8 == 0):
-            dyb = Fn.to_bf16(dy2) if (N % 4 == 0 or Fn.precision() == "fp32") else dy2.to(BF16)
+            dyb = Fn.operand(dy2) if (N % 4 == 0 or Fn.precision() == "fp32") else dy2.to(BF16)
         if ctx.needs_input_grad[0]:
             wt = weight_t_bf16(weight)                           # [K, Npad]
             dx = Fn.gemm(dyb, wt, out_dtype=F32, k=N).view(ctx.x_shape)
@@ -120,8 +120,8 @@ class LinearFn(torch.autograd.Function):
             if N % 8 == 0 and K % 8 == 0 and x2.stride(0) % 8 == 0:
                 dw = Fn.gemm_tn(dyb, x2)                         # transposing LDS reads + split-m: no dY^T / X^T passes
             else:
-                dyt = Fn.transpose_to_bf16(dy2)                  # [N, Mpad]
-                xt = Fn.transpose_to_bf16(x2)                    # [K, Mpad]
+                dyt = Fn.operand_t(dy2)                  # [N, Mpad]
+                xt = Fn.operand_t(x2)                    # [K, Mpad]
                 dw = Fn.gemm(dyt, xt, out_dtype=F32, k=dyt.shape[1])  # [N, K]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = Fn.colsum(dy2)
@@ -142,7 +142,7 @@ class LinearScaleResidualFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, lam, res):
-        xb = x if x.dtype == BF16 else Fn.to_bf16(x.contiguous())
+        xb = x if x.dtype == BF16 else Fn.operand(x.contiguous())
         x2 = xb.reshape(-1, xb.shape[-1])
         N, K = weight.shape
         res2 = res.reshape(-1, N).contiguous()
@@ -156,7 +156,7 @@ class LinearScaleResidualFn(torch.autograd.Function):
         x2, weight, bias, lam = ctx.saved_tensors
         N, K = weight.shape
         dy2 = dy.reshape(-1, N).contiguous()
-        dyb = Fn.to_bf16(dy2)
+        dyb = Fn.operand(dy2)
         G = Fn.gemm_tn(dyb, x2)                                  # [N, K]
         s = Fn.colsum(dy2)
         lam_d, w_d = lam.detach(), weight.detach()
@@ -165,7 +165,7 @@ class LinearScaleResidualFn(torch.autograd.Function):
         dlam = (w_d * G).sum(dim=1) + bias.detach() * s
         dx = None
         if ctx.needs_input_grad[0]:
-            wl_t = Fn.transpose_to_bf16((lam_d[:, None] * w_d).contiguous())         # [K, N] bf16: dX = dY (lam * W)
+            wl_t = Fn.operand_t((lam_d[:, None] * w_d).contiguous())         # [K, N] bf16: dX = dY (lam * W)
             dx = Fn.gemm(dyb, wl_t, out_dtype=F32, k=N).view(ctx.x_shape)
         return dx, dw, db, dlam, dy
 
@@ -183,8 +183,8 @@ class InProjFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xq, xkv, weight, bias, d):
         K = weight.shape[1]
-        q2 = Fn.to_bf16(xq.contiguous()).reshape(-1, K)
-        kv2 = Fn.to_bf16(xkv.contiguous()).reshape(-1, K)
+        q2 = Fn.operand(xq.contiguous()).reshape(-1, K)
+        kv2 = Fn.operand(xkv.contiguous()).reshape(-1, K)
         wb = weight_bf16(weight)
         Q = Fn.gemm(q2, wb[:d], bias=bias[:d], out_dtype=F32, k=K)
         KV = Fn.gemm(kv2, wb[d:], bias=bias[d:], out_dtype=F32, k=K)
@@ -198,7 +198,7 @@ class InProjFn(torch.autograd.Function):
         d, (N3, K) = ctx.d, weight.shape
         dq2 = dQ.reshape(-1, d).contiguous()
         dkv2 = dKV.reshape(-1, N3 - d).contiguous()
-        dqb, dkvb = Fn.to_bf16(dq2), Fn.to_bf16(dkv2)
+        dqb, dkvb = Fn.operand(dq2), Fn.operand(dkv2)
         dxq = dxkv = dw = db = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             wt = weight_t_bf16(weight)                                   # [K, 3d]

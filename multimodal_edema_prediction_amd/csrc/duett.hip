@@ -214,10 +214,11 @@ __global__ __launch_bounds__(128) void psi_embed_event_kernel(const float* __res
     // wave cycles in s_waitcnt, 48 us.)
     extern __shared__ __attribute__((aligned(16))) float tile[];          // [PE_NB][(T+1)*E] the rows
     __shared__ __attribute__((aligned(16))) float sl0[HD * 8], sw4[HD * E], sb4[E];
-    __shared__ float s_rn[PE_NB], s_tab[PE_NB][E], s_hid[256], s_part[2][E];
+    __shared__ float s_rn[PE_NB], s_tab[PE_NB][E], s_hid[256], s_part[2][E], s_nobs[64];
     const int v = blockIdx.y, b0 = blockIdx.x * PE_NB;
     const int nb = min(PE_NB, B - b0);
     const int T1 = T + 1, F = 2 * V + 1, D = T1 * E, D4 = D >> 2;
+    if (threadIdx.x < 64) s_nobs[threadIdx.x] = nobs_table[min((int)threadIdx.x, nobs_rows - 1)];
     if (v < V) {
         for (int i = threadIdx.x; i < HD * 8 / 4; i += 128) ((float4*)sl0)[i] = ((const float4*)(l0 + (size_t)v * HD * 8))[i];
         for (int i = threadIdx.x; i < HD * E / 4; i += 128) ((float4*)sw4)[i] = ((const float4*)(w4t + (size_t)v * HD * E))[i];
@@ -251,29 +252,34 @@ __global__ __launch_bounds__(128) void psi_embed_event_kernel(const float* __res
         float val[PE_NB], nob[PE_NB];
         const float* src[PE_NB];
         bool any_mlp = false;
+        // every input this lane needs, loaded up front and unconditionally (12 independent loads in flight): behind the
+        // data-dependent branches below they formed a chain of three L2 round trips per cell, four cells in a row
+        float msk[PE_NB], cnt[PE_NB];
+#pragma unroll
+        for (int bb = 0; bb < PE_NB; ++bb) {
+            msk[bb] = 1.f; cnt[bb] = -1.f; val[bb] = 0.f;
+            if (bb < nb && t < T) {
+                const float* row = xs_ts + ((size_t)(b0 + bb) * T + t) * F;
+                msk[bb] = row[2 * V];
+                if (v < V) { cnt[bb] = row[V + v]; val[bb] = row[v]; }
+            }
+        }
 #pragma unroll
         for (int bb = 0; bb < PE_NB; ++bb) {
             src[bb] = nullptr;
-            val[bb] = nob[bb] = 0.f;
-            if (bb >= nb) { src[bb] = special; continue; }             // no such row: computed on zeros, never stored
+            nob[bb] = 0.f;
+            if (bb >= nb) { src[bb] = special; continue; }             // no such row: never stored
             if (t == T) {
                 src[bb] = special + E;                                   // REP row                                 (model :58-60)
+            } else if (msk[bb] == 1.0f) {
+                src[bb] = special;                                       // masked timestep                         (model :61-64)
+            } else if (v == V) {
+                src[bb] = s_tab[bb];                                     // static column                           (model :57)
+            } else if (cnt[bb] == -1.0f) {
+                src[bb] = special;                                       // masked event (SSL only)                 (model :65-66)
             } else {
-                const float* row = xs_ts + ((size_t)(b0 + bb) * T + t) * F;
-                if (row[2 * V] == 1.0f) {
-                    src[bb] = special;                                   // masked timestep                         (model :61-64)
-                } else if (v == V) {
-                    src[bb] = s_tab[bb];                                 // static column                           (model :57)
-                } else {
-                    const float cnt = row[V + v];
-                    if (cnt == -1.0f) {
-                        src[bb] = special;                               // masked event (SSL only)                 (model :65-66)
-                    } else {
-                        val[bb] = row[v];
-                        nob[bb] = nobs_table[min(max((int)cnt, 0), nobs_rows - 1)];    // .to(int).clip(0, 15) (model :41)
-                        any_mlp = true;
-                    }
-                }
+                nob[bb] = s_nobs[min(max((int)cnt[bb], 0), nobs_rows - 1)];            // .to(int).clip(0, 15) (model :41)
+                any_mlp = true;
             }
         }
         if (v < V && __any(any_mlp)) {
@@ -425,7 +431,7 @@ int launch_psi_embed_event(const MedpDuettWeights* w, const float* xs_static, co
                            int T, hipStream_t s) {
     const int V = w->n_vars, V1 = V + 1, T1 = T + 1, E = w->d_embedding;
     MEDP_CHECK_ARG(w->emb_l0 && w->emb_w4t, "duett: emb_l0 / emb_w4t (transposed weight layout) missing");
-    MEDP_CHECK_ARG(w->d_hidden_tab <= 256, "duett: tab encoder hidden size above 256");
+    MEDP_CHECK_ARG(w->d_hidden_tab <= 256 && w->n_obs_rows >= 1 && w->n_obs_rows <= 64, "duett: tab encoder hidden size above 256 / n_obs table above 64 rows");
     const size_t lds = (size_t)PE_NB * T1 * E * sizeof(float);
     MEDP_CHECK_ARG(lds <= 120 * 1024, "duett: 4 rows of (T+1)*E floats must fit the embed kernel's LDS tile");
     MEDP_ONCE_PER_DEVICE({

@@ -54,10 +54,24 @@ def _ld(t: torch.Tensor) -> int:
     return t.stride(0)
 
 
+def operand(x: torch.Tensor) -> torch.Tensor:
+    """An activation / gradient as a GEMM operand of the op-level paths: bf16 (HIP cast kernel); in fp32 mode the tensor itself."""
+    return x.contiguous() if _PRECISION == "fp32" else to_bf16(x)
+
+
+def operand_t(x: torch.Tensor) -> torch.Tensor:
+    """[R, C] -> the transposed GEMM operand [C, Rpad8]: bf16, or fp32 in fp32 mode (same zero-padded shape)."""
+    if _PRECISION != "fp32":
+        return transpose_to_bf16(x)
+    x2 = _2d(x)
+    R, C = x2.shape
+    y = torch.zeros((C, (R + 7) // 8 * 8), dtype=F32, device=x.device)
+    y[:, :R] = x2.to(F32).t()
+    return y
+
+
 def to_bf16(x: torch.Tensor) -> torch.Tensor:
-    """fp32 [.., C] -> the GEMM operand type: bf16 (HIP cast kernel); in fp32 mode the tensor itself."""
-    if _PRECISION == "fp32":
-        return x.contiguous()
+    """fp32 [.., C] -> bf16 (HIP cast kernel), whatever the precision mode (the frozen whole-module paths are bf16 by construction)."""
     x2 = _2d(x)
     y = torch.empty(x2.shape, dtype=BF16, device=x.device)
     check(lib().medp_cast_f32_bf16(ptr(x2), _ld(x2), ptr(y), y.stride(0), x2.shape[0], x2.shape[1], stream()), "cast")
@@ -69,10 +83,6 @@ def transpose_to_bf16(x: torch.Tensor) -> torch.Tensor:
     x2 = _2d(x)
     R, C = x2.shape
     Rp = (R + 7) // 8 * 8
-    if _PRECISION == "fp32":                      # layout plumbing only (the fp32 GEMM has no alignment needs; same padded shape)
-        y = torch.zeros((C, Rp), dtype=F32, device=x.device)
-        y[:, :R] = x2.to(F32).t()
-        return y
     y = torch.zeros((C, Rp), dtype=BF16, device=x.device) if Rp != R else torch.empty((C, Rp), dtype=BF16, device=x.device)
     check(lib().medp_transpose_to_bf16(ptr(x2), int(x2.dtype == BF16), _ld(x2), ptr(y), Rp, R, C, stream()), "transpose")
     return y

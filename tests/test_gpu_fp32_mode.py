@@ -47,7 +47,7 @@ def test_fp32_gemms(M, N, K):
         dy = torch.randn(M, N, generator=g)
         dw = Fn.gemm_tn(dy.to(DEV), ad)
     want = torch.nn.functional.gelu(a.double() @ w.double().T + bias.double()) * scale.double() + res.double()
-    _close(y, want, 2e-6, 2e-6, "gemm_f32_nt")
+    _close(y, want, 2e-6, 2e-5, "gemm_f32_nt")              # K fp32 FMAs per output: ~sqrt(K) * 2^-24 * |a||w|
     _close(dw, dy.double().T @ a.double(), 5e-6, 5e-6 * math.sqrt(M), "gemm_f32_tn")
     assert Fn.precision() == "bf16"                     # the context manager restores the mode
 
