@@ -198,8 +198,8 @@ struct TabWeights {
     const float *xs, *w0, *b0, *s, *sh, *w4, *b4;
     int Ds, Hd;
 };
-constexpr int PE_NB = 4;      // batch elements (event-view rows of one variable) per workgroup of the fused embed kernel
-template <int E, int HD>
+// PE_NB = batch elements (event-view rows of one variable) per workgroup of the fused embed kernel = cells per lane
+template <int E, int HD, int PE_NB>
 __global__ __launch_bounds__(128) void psi_embed_event_kernel(const float* __restrict__ xs_ts, const float* __restrict__ l0,
                                                               const float* __restrict__ w4t, const float* __restrict__ b4,
                                                               const float* __restrict__ nobs_table, int nobs_rows, const TabWeights tw,
@@ -207,11 +207,14 @@ __global__ __launch_bounds__(128) void psi_embed_event_kernel(const float* __res
                                                               const float* __restrict__ event_emb, const float* __restrict__ g_norm,
                                                               float norm_eps, float* __restrict__ xe, bf16_t* __restrict__ h,
                                                               float* __restrict__ psi0_out, int B, int T, int V) {
-    // A workgroup = one variable v x PE_NB consecutive batch elements: the variable's MLP (7.5 KB) is staged in LDS ONCE for
-    // 4 x (T+1) cells, and every lane carries FOUR cells (one per batch element) through the hidden-unit loop, so one broadcast
-    // LDS read of a weight feeds four cells' FMAs.  (One cell per lane made the CU's single LDS pipe the bound — 11 reads per
-    // 16 VALU instructions, 50 us at cfg3; weights by scalar loads instead left the waves parked on SMEM latency: 79 % of the
-    // wave cycles in s_waitcnt, 48 us.)
+    // A workgroup = one variable v x PE_NB consecutive batch elements (PE_NB cells per lane, one per batch element); the
+    // variable's MLP (7.5 KB) is staged in LDS once per workgroup and read back by broadcast 16-B reads.  What bounds it: every
+    // lane needs the same 29 floats per hidden unit, and a wave-wide LDS read returns 1 KB through the CU's 128-B/clk LDS
+    // return path whether or not the lanes share an address: 64 hidden units x 8 reads x 8 clocks per wave = 38 us of LDS time
+    // per CU at cfg3 (measured 44 us with PE_NB = 1).  Tried and measured: weights by scalar loads into SGPRs (48 us, 79 % of
+    // the wave cycles parked in s_waitcnt: SMEM returns out of order, so only lgkmcnt(0) is available and the loads of a hidden
+    // unit cannot be overlapped with the previous one's FMAs); 2 / 4 cells per lane to amortise the reads (53 / 77 us: the
+    // launch then has 3 / 1.5 waves per SIMD and the long waves no longer hide each other's latency).
     extern __shared__ __attribute__((aligned(16))) float tile[];          // [PE_NB][(T+1)*E] the rows
     __shared__ __attribute__((aligned(16))) float sl0[HD * 8], sw4[HD * E], sb4[E];
     __shared__ float s_rn[PE_NB], s_tab[PE_NB][E], s_hid[256], s_part[2][E], s_nobs[64];
@@ -427,24 +430,37 @@ int launch_swap_add_norm(const float* in, const float* rnorm, const float* g_pre
     return 0;
 }
 
-int launch_psi_embed_event(const MedpDuettWeights* w, const float* xs_static, const float* xs_ts, float* xe, void* h, float* psi0_out, int B,
-                           int T, hipStream_t s) {
+template <int NB>
+int launch_psi_embed_event_nb(const MedpDuettWeights* w, const float* xs_static, const float* xs_ts, float* xe, void* h, float* psi0_out, int B,
+                              int T, hipStream_t s) {
     const int V = w->n_vars, V1 = V + 1, T1 = T + 1, E = w->d_embedding;
-    MEDP_CHECK_ARG(w->emb_l0 && w->emb_w4t, "duett: emb_l0 / emb_w4t (transposed weight layout) missing");
-    MEDP_CHECK_ARG(w->d_hidden_tab <= 256 && w->n_obs_rows >= 1 && w->n_obs_rows <= 64, "duett: tab encoder hidden size above 256 / n_obs table above 64 rows");
-    const size_t lds = (size_t)PE_NB * T1 * E * sizeof(float);
-    MEDP_CHECK_ARG(lds <= 120 * 1024, "duett: 4 rows of (T+1)*E floats must fit the embed kernel's LDS tile");
+    const size_t lds = (size_t)NB * T1 * E * sizeof(float);
+    if (lds > 120 * 1024) return -2;
     MEDP_ONCE_PER_DEVICE({
-        (void)hipFuncSetAttribute((const void*)psi_embed_event_kernel<24, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+        (void)hipFuncSetAttribute((const void*)psi_embed_event_kernel<24, 64, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
     });
     const TabWeights tw{xs_static, (const float*)w->tab_w0, (const float*)w->tab_b0, (const float*)w->tab_bn_scale, (const float*)w->tab_bn_shift,
                         (const float*)w->tab_w4, (const float*)w->tab_b4, w->n_static, w->d_hidden_tab};
-    psi_embed_event_kernel<24, 64><<<dim3((B + PE_NB - 1) / PE_NB, V1), 128, lds, s>>>(
+    psi_embed_event_kernel<24, 64, NB><<<dim3((B + NB - 1) / NB, V1), 128, lds, s>>>(
         xs_ts, (const float*)w->emb_l0, (const float*)w->emb_w4t, (const float*)w->emb_b4, (const float*)w->n_obs_table, w->n_obs_rows, tw,
         (const float*)w->special, (const float*)w->event_embedding, (const float*)w->event_enc[0].g_attn, w->norm_eps, xe, (bf16_t*)h, psi0_out,
         B, T, V);
     MEDP_LAUNCH_CHECK("duett psi_embed_event");
     return 0;
+}
+
+int launch_psi_embed_event(const MedpDuettWeights* w, const float* xs_static, const float* xs_ts, float* xe, void* h, float* psi0_out, int B,
+                           int T, hipStream_t s) {
+    MEDP_CHECK_ARG(w->emb_l0 && w->emb_w4t, "duett: emb_l0 / emb_w4t (transposed weight layout) missing");
+    MEDP_CHECK_ARG(w->d_hidden_tab <= 256 && w->n_obs_rows >= 1 && w->n_obs_rows <= 64, "duett: tab encoder hidden size above 256 / n_obs table above 64 rows");
+    // rows (= cells per lane) per workgroup.  Measured at cfg3 (tools/time_embed_variants.py): 1 -> 44 us, 2 -> 53 us, 4 -> 77 us:
+    // fewer, longer waves lose more than the amortised weight reads win; 1 is the default.
+    static const int nb = [] { const char* e = getenv("MEDP_PSI_NB"); return e ? atoi(e) : 1; }();
+    int rc = nb >= 4 ? launch_psi_embed_event_nb<4>(w, xs_static, xs_ts, xe, h, psi0_out, B, T, s)
+           : nb >= 2 ? launch_psi_embed_event_nb<2>(w, xs_static, xs_ts, xe, h, psi0_out, B, T, s) : -2;
+    if (rc == -2) rc = launch_psi_embed_event_nb<1>(w, xs_static, xs_ts, xe, h, psi0_out, B, T, s);   // long rows: one per workgroup
+    MEDP_CHECK_ARG(rc != -2, "duett: a (T+1)*E row does not fit the embed kernel's LDS tile");
+    return rc;
 }
 
 struct DuettWs {
