@@ -318,10 +318,11 @@ int medp_glinear_bwd(const float* dy, const float* x, const float* W, float* dx,
                      int K, int N, void* stream);
 /* BatchNormLastDim over the R rows of every group (duett/duett.py:11-22): batch_stats=1 train (biased var normalises,
  * unbiased updates running), 0 eval.  save_mean/save_var [G,C] feed the backward. */
+size_t medp_gbn_workspace_bytes(int G, int R, int C);   /* per-chunk partial sums of the two-stage (deterministic) row reductions */
 int medp_gbn_fwd(const float* x, const float* w, const float* b, float* running_mean, float* running_var, float* y, float* save_mean,
-                 float* save_var, int G, int R, int C, float eps, float momentum, int batch_stats, void* stream);
+                 float* save_var, int G, int R, int C, float eps, float momentum, int batch_stats, float* workspace, void* stream);
 int medp_gbn_bwd(const float* dy, const float* x, const float* w, const float* save_mean, const float* save_var, float* dx, float* dw,
-                 float* db, int G, int R, int C, float eps, int batch_stats, void* stream);
+                 float* db, int G, int R, int C, float eps, int batch_stats, float* workspace, void* stream);
 int medp_act_fwd(const float* x, float* y, long long n, int mode /*0 relu, 1 tanh*/, void* stream);
 int medp_act_bwd(const float* dy, const float* y, float* dx, long long n, int mode, void* stream);
 /* (value, n_obs_embedding[clip(int(count),0,15)]) pairs per variable, zero-padded to KP columns (model :41-52) */

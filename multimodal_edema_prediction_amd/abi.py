@@ -111,8 +111,9 @@ SIGNATURES = {
     "medp_glinear_fwd": (I, [P, P, P, P, I, I, I, I, P]),
     "medp_glinear_bwd_workspace_bytes": (SZ, [I, I, I, I]),
     "medp_glinear_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, P]),
-    "medp_gbn_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, F, F, I, P]),
-    "medp_gbn_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, F, I, P]),
+    "medp_gbn_workspace_bytes": (SZ, [I, I, I]),
+    "medp_gbn_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, F, F, I, P, P]),
+    "medp_gbn_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, F, I, P, P]),
     "medp_act_fwd": (I, [P, P, LL, I, P]),
     "medp_act_bwd": (I, [P, P, P, LL, I, P]),
     "medp_embed_inputs_fwd": (I, [P, P, I, P, I, I, I, I, P]),

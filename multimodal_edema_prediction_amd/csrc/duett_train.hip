@@ -12,58 +12,71 @@ inline int grid_for(size_t work_items) { return (int)min((size_t)4096, max((size
 
 // ---- grouped tiny linear: y[g][r][n] = b[g][n] + sum_k W[g][n][k] x[g][r][k]      (N*K <= 8192) ---------------------
 constexpr int GLINEAR_MAX_FLOATS = 36000;     // weights (+ bias) of one group held in LDS: 144 KB of the CU's 160 KB
+// y[g][r][n] = b[g][n] + sum_k W[g][n][k] x[g][r][k].  ONE OUTPUT ELEMENT PER THREAD, consecutive threads = consecutive n of a row,
+// so every store instruction writes one contiguous span of y (the first form gave a thread a whole row: its 64 stores each
+// scattered 64 lanes 256 B apart — 193 us for a 75-MB result at cfg3).  The group's weights sit in LDS with rows padded to
+// K + 1 floats (lanes differ in n: stride K would put them all in one bank); x is read through the cache (the N threads of a
+// row read the same K floats).  Products are summed in ascending k from the bias, as before: same values.
 __global__ __launch_bounds__(256) void glinear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
                                                           float* __restrict__ y, int R, int K, int N) {
-    extern __shared__ float sw[];            // N*K weights + N bias
-    const int g = blockIdx.y;
-    for (int i = threadIdx.x; i < N * K; i += 256) sw[i] = W[(size_t)g * N * K + i];
-    for (int i = threadIdx.x; i < N; i += 256) sw[N * K + i] = b ? b[(size_t)g * N + i] : 0.f;
+    extern __shared__ float sw[];            // N*(K+1) weights + N bias
+    const int g = blockIdx.y, KP = K + 1;
+    for (int i = threadIdx.x; i < N * K; i += 256) sw[(i / K) * KP + i % K] = W[(size_t)g * N * K + i];
+    for (int i = threadIdx.x; i < N; i += 256) sw[N * KP + i] = b ? b[(size_t)g * N + i] : 0.f;
     __syncthreads();
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= R) return;
-    const float* xr = x + ((size_t)g * R + r) * K;
-    float* yr = y + ((size_t)g * R + r) * N;
-    for (int n = 0; n < N; ++n) {
-        float a = sw[N * K + n];
-        const float* wr = sw + n * K;
+    const size_t total = (size_t)R * N;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int r = (int)(idx / N), n = (int)(idx - (size_t)r * N);
+        const float* xr = x + ((size_t)g * R + r) * K;
+        const float* wr = sw + n * KP;
+        float a = sw[N * KP + n];
         for (int k = 0; k < K; ++k) a += wr[k] * xr[k];
-        yr[n] = a;
+        y[(size_t)g * total + idx] = a;
     }
 }
-// dx[g][r][k] = sum_n dy[g][r][n] W[g][n][k]
+// dx[g][r][k] = sum_n dy[g][r][n] W[g][n][k]: one output element per thread, consecutive threads = consecutive k (LDS reads
+// conflict-free, stores contiguous); ascending n as before.
 __global__ __launch_bounds__(256) void glinear_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ W, float* __restrict__ dx,
                                                              int R, int K, int N) {
     extern __shared__ float sw[];
     const int g = blockIdx.y;
     for (int i = threadIdx.x; i < N * K; i += 256) sw[i] = W[(size_t)g * N * K + i];
     __syncthreads();
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= R) return;
-    const float* dr = dy + ((size_t)g * R + r) * N;
-    float* xr = dx + ((size_t)g * R + r) * K;
-    for (int k = 0; k < K; ++k) {
+    const size_t total = (size_t)R * K;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int r = (int)(idx / K), k = (int)(idx - (size_t)r * K);
+        const float* dr = dy + ((size_t)g * R + r) * N;
         float a = 0.f;
         for (int n = 0; n < N; ++n) a += dr[n] * sw[n * K + k];
-        xr[k] = a;
+        dx[(size_t)g * total + idx] = a;
     }
 }
 // partial[g][chunk][n*K+k] = sum_{r in chunk} dy[r][n] x[r][k] ;  partial_b[g][chunk][n] = sum dy[r][n]
+// The chunk's dy and x rows are staged in LDS with coalesced loads (they are contiguous spans), then every thread walks the rows
+// for its (n, k) outputs out of LDS — the first form read both operands straight from global memory inside the row loop, two
+// dependent loads per row and output (126 us per launch at cfg3).  Same summation order (ascending r): same values.
 __global__ __launch_bounds__(256) void glinear_bwd_dw_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                      float* __restrict__ pw, float* __restrict__ pb, int R, int K, int N,
                                                                      int rows_per_chunk) {
+    extern __shared__ float sm[];            // [rows][N] dy, then [rows][K] x
     const int g = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
-    const int r0 = chunk * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
-    const float* dyg = dy + (size_t)g * R * N;
-    const float* xg = x + (size_t)g * R * K;
+    const int r0 = chunk * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk), nr = max(r1 - r0, 0);
+    float* sdy = sm;
+    float* sx = sm + (size_t)rows_per_chunk * N;
+    const float* dyg = dy + ((size_t)g * R + r0) * N;
+    const float* xg = x + ((size_t)g * R + r0) * K;
+    for (int i = threadIdx.x; i < nr * N; i += 256) sdy[i] = dyg[i];
+    for (int i = threadIdx.x; i < nr * K; i += 256) sx[i] = xg[i];
+    __syncthreads();
     for (int i = threadIdx.x; i < N * K; i += 256) {
         const int n = i / K, k = i % K;
         float a = 0.f;
-        for (int r = r0; r < r1; ++r) a += dyg[(size_t)r * N + n] * xg[(size_t)r * K + k];
+        for (int r = 0; r < nr; ++r) a += sdy[r * N + n] * sx[r * K + k];
         pw[((size_t)g * nchunk + chunk) * N * K + i] = a;
     }
     for (int n = threadIdx.x; n < N; n += 256) {
         float a = 0.f;
-        for (int r = r0; r < r1; ++r) a += dyg[(size_t)r * N + n];
+        for (int r = 0; r < nr; ++r) a += sdy[r * N + n];
         pb[((size_t)g * nchunk + chunk) * N + n] = a;
     }
 }
@@ -78,25 +91,51 @@ __global__ __launch_bounds__(256) void sum_chunks_kernel(const float* __restrict
 }
 
 // ---- grouped BatchNorm over rows: x [G][R][C], statistics per (g, c) ------------------------------------------------
-// stats kernel: block = 64 columns x 4 row-lanes, loops every row (two sweeps: mean, then centred second moment)
-__global__ __launch_bounds__(256) void gbn_stats_kernel(const float* __restrict__ x, float* __restrict__ mean, float* __restrict__ var, int R, int C) {
-    __shared__ float red[4][64];
-    const int g = blockIdx.y, cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+// Two stages, deterministic: (1) workgroups of 64 columns x 4 row-lanes each take a CHUNK of GBN_RPC rows of one group and
+// write the chunk's shifted sums  S1 = sum (x - p),  S2 = sum (x - p)^2  (pivot p = the group's first row: no cancellation
+// in  var = S2/R - (S1/R)^2  for activations whose mean dwarfs their spread); (2) one thread per (g, c) adds the chunks in
+// order.  The first form ran ONE workgroup per group over all R rows (48 workgroups on 256 CUs, two dependent sweeps): 423 us
+// for a 75-MB operand at cfg3; the backward sums kernel had the same shape (427 us).
+constexpr int GBN_RPC = 128;
+inline int gbn_chunks(int R) { return (R + GBN_RPC - 1) / GBN_RPC; }
+__global__ __launch_bounds__(256) void gbn_stats_partial_kernel(const float* __restrict__ x, float* __restrict__ part, int R, int C) {
+    __shared__ float red[2][4][64];
+    const int g = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x, cb = blockIdx.z * 64;
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = cb + cl;
     const float* xg = x + (size_t)g * R * C;
-    float s = 0.f;
-    if (c < C) for (int r = rl; r < R; r += 4) s += xg[(size_t)r * C + c];
-    red[rl][cl] = s;
-    __syncthreads();
-    const float mu = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) / (float)R;
-    __syncthreads();
-    float q = 0.f;
-    if (c < C) for (int r = rl; r < R; r += 4) { const float d = xg[(size_t)r * C + c] - mu; q += d * d; }
-    red[rl][cl] = q;
+    const int r0 = chunk * GBN_RPC, r1 = min(R, r0 + GBN_RPC);
+    float a = 0.f, q = 0.f;
+    if (c < C) {
+        const float p = xg[c];
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const float d = xg[(size_t)r * C + c] - p;
+            a += d;
+            q += d * d;
+        }
+    }
+    red[0][rl][cl] = a;
+    red[1][rl][cl] = q;
     __syncthreads();
     if (rl == 0 && c < C) {
-        mean[(size_t)g * C + c] = mu;
-        var[(size_t)g * C + c] = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) / (float)R;   // biased
+        float* o = part + (((size_t)g * nchunk + chunk) * 2) * C;
+        o[c] = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+        o[C + c] = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
     }
+}
+__global__ __launch_bounds__(256) void gbn_stats_final_kernel(const float* __restrict__ x, const float* __restrict__ part, float* __restrict__ mean,
+                                                              float* __restrict__ var, int G, int R, int C, int nchunk) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= G * C) return;
+    const int g = i / C, c = i - g * C;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < nchunk; ++k) {
+        const float* o = part + (((size_t)g * nchunk + k) * 2) * C;
+        s1 += o[c];
+        s2 += o[C + c];
+    }
+    const float m1 = s1 / (float)R;
+    mean[i] = x[(size_t)g * R * C + c] + m1;
+    var[i] = fmaxf(s2 / (float)R - m1 * m1, 0.f);             // biased
 }
 // running = (1-m)*running + m*batch  (unbiased variance), num_batches_tracked handled by the caller
 __global__ __launch_bounds__(256) void gbn_running_kernel(const float* __restrict__ mean, const float* __restrict__ var, float* __restrict__ rmean,
@@ -116,16 +155,18 @@ __global__ __launch_bounds__(256) void gbn_apply_kernel(const float* __restrict_
         y[i] = (x[i] - mean[gc]) * rsqrtf(var[gc] + eps) * w[gc] + b[gc];
     }
 }
-// sums for backward: s1[g][c] = sum_r dy ; s2[g][c] = sum_r dy * xhat
-__global__ __launch_bounds__(256) void gbn_bwd_sums_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
-                                                           const float* __restrict__ var, float* __restrict__ s1, float* __restrict__ s2, int R,
-                                                           int C, float eps) {
+// sums for backward: s1[g][c] = sum_r dy ; s2[g][c] = sum_r dy * xhat — per chunk of rows, then added in order (see above)
+__global__ __launch_bounds__(256) void gbn_bwd_sums_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                   const float* __restrict__ mean, const float* __restrict__ var,
+                                                                   float* __restrict__ part, int R, int C, float eps) {
     __shared__ float red[2][4][64];
-    const int g = blockIdx.y, cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    const int g = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x, cb = blockIdx.z * 64;
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = cb + cl;
+    const int r0 = chunk * GBN_RPC, r1 = min(R, r0 + GBN_RPC);
     float a = 0.f, q = 0.f;
     if (c < C) {
         const float mu = mean[(size_t)g * C + c], rs = rsqrtf(var[(size_t)g * C + c] + eps);
-        for (int r = rl; r < R; r += 4) {
+        for (int r = r0 + rl; r < r1; r += 4) {
             const size_t i = ((size_t)g * R + r) * C + c;
             a += dy[i];
             q += dy[i] * (x[i] - mu) * rs;
@@ -135,9 +176,24 @@ __global__ __launch_bounds__(256) void gbn_bwd_sums_kernel(const float* __restri
     red[1][rl][cl] = q;
     __syncthreads();
     if (rl == 0 && c < C) {
-        s1[(size_t)g * C + c] = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
-        s2[(size_t)g * C + c] = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+        float* o = part + (((size_t)g * nchunk + chunk) * 2) * C;
+        o[c] = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+        o[C + c] = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
     }
+}
+__global__ __launch_bounds__(256) void gbn_bwd_sums_final_kernel(const float* __restrict__ part, float* __restrict__ s1, float* __restrict__ s2,
+                                                                 int G, int C, int nchunk) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= G * C) return;
+    const int g = i / C, c = i - g * C;
+    float a = 0.f, q = 0.f;
+    for (int k = 0; k < nchunk; ++k) {
+        const float* o = part + (((size_t)g * nchunk + k) * 2) * C;
+        a += o[c];
+        q += o[C + c];
+    }
+    s1[i] = a;
+    s2[i] = q;
 }
 // train: dx = w*rstd*(dy - s1/R - xhat*s2/R) ; eval (batch_stats == 0): dx = w*rstd*dy
 __global__ __launch_bounds__(256) void gbn_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
@@ -241,41 +297,39 @@ __global__ __launch_bounds__(256) void psi_assemble_fwd_kernel(const float* __re
 __global__ __launch_bounds__(256) void psi_assemble_bwd_kernel(const float* __restrict__ xs, const float* __restrict__ dpsi, float* __restrict__ d_var,
                                                                float* __restrict__ d_tab, float* __restrict__ d_special_part, int B, int T, int V,
                                                                int E) {
-    // Deterministic: pass 1 scatters d_var and records each cell's kind; pass 2 gives every (kind, e) sum to ONE thread, which
-    // walks the batch element's cells in index order (the sums are 3 x E values over (T+1)(V+1) cells: tiny).
-    extern __shared__ unsigned char kinds[];          // [(T+1)*(V+1)]
-    const int b = blockIdx.x;
+    // Deterministic and coalesced: a thread = (cell lane, 16-B piece of the cell); it walks every NL-th cell of this batch element,
+    // scatters d_var and keeps three private float4 sums (static column / masked / REP cells); the NL cell lanes are then added in
+    // a fixed order through LDS.  (LDS float atomics, the first form, made the sums depend on the waves' timing; a one-thread-per-
+    // sum walk over all cells was deterministic but took 264 us at cfg3.)
+    extern __shared__ __attribute__((aligned(16))) float red[];          // [NL][3][E]
+    const int b = blockIdx.x, E4 = E >> 2;
+    const int NL = 256 / E4;                                              // cell lanes (42 at E = 24)
+    const int cl = threadIdx.x / E4, e4 = threadIdx.x - cl * E4;
     const int cells = (T + 1) * (V + 1);
-    for (int cidx = threadIdx.x; cidx < cells; cidx += 256) {
-        const int t = cidx / (V + 1), v = cidx % (V + 1);
-        const int kind = psi_cell_kind(xs, b, t, v, T, V);
-        kinds[cidx] = (unsigned char)kind;
-        if (v < V && t < T) {
-            const float* g = dpsi + (((size_t)b * (T + 1) + t) * (V + 1) + v) * E;
-            float* o = d_var + (((size_t)v * B + b) * T + t) * E;
-            for (int e = 0; e < E; ++e) o[e] = kind == 0 ? g[e] : 0.f;
+    float4 acc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cl < NL) {
+        for (int cidx = cl; cidx < cells; cidx += NL) {
+            const int t = cidx / (V + 1), v = cidx - t * (V + 1);
+            const int kind = psi_cell_kind(xs, b, t, v, T, V);
+            const float4 g = *(const float4*)(dpsi + ((size_t)b * cells + cidx) * E + e4 * 4);
+            if (v < V && t < T)
+                *(float4*)(d_var + (((size_t)v * B + b) * T + t) * E + e4 * 4) = kind == 0 ? g : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (kind == k + 1) acc[k] = make_float4(acc[k].x + g.x, acc[k].y + g.y, acc[k].z + g.z, acc[k].w + g.w);
         }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) *(float4*)(red + ((size_t)cl * 3 + k) * E + e4 * 4) = acc[k];
     }
     __syncthreads();
-    // 3*E sums, each split over `parts` threads by cell-index stripes, combined in a fixed order through LDS
-    const int nsum = 3 * E, parts = 256 / nsum > 0 ? 256 / nsum : 1;
-    __shared__ float partial[256];
-    const int id = threadIdx.x;
-    float a = 0.f;
-    if (id < nsum * parts) {
-        const int sidx = id % nsum, part = id / nsum, kind = sidx / E + 1, e = sidx % E;
-        const float* base = dpsi + (size_t)b * cells * E + e;
-        for (int cidx = part; cidx < cells; cidx += parts)
-            if (kinds[cidx] == kind) a += base[(size_t)cidx * E];
-    }
-    partial[id] = a;
-    __syncthreads();
-    if (id < nsum) {
+    if ((int)threadIdx.x < 3 * E) {
+        const int k = threadIdx.x / E, e = threadIdx.x - k * E;
         float tot = 0.f;
-        for (int part = 0; part < parts; ++part) tot += partial[part * nsum + id];
-        const int kind = id / E, e = id % E;
-        if (kind == 0) d_tab[(size_t)b * E + e] = tot;
-        else d_special_part[((size_t)b * 2 + (kind - 1)) * E + e] = tot;
+        for (int l = 0; l < NL; ++l) tot += red[((size_t)l * 3 + k) * E + e];
+        if (k == 0) d_tab[(size_t)b * E + e] = tot;
+        else d_special_part[((size_t)b * 2 + (k - 1)) * E + e] = tot;
     }
 }
 
@@ -307,11 +361,11 @@ int dw_chunks(int R) { return max(1, min(64, R / 96)); }
 }  // namespace
 
 extern "C" int medp_glinear_fwd(const float* x, const float* W, const float* b, float* y, int G, int R, int K, int N, void* stream) {
-    MEDP_CHECK_ARG(x && W && y && G > 0 && R > 0 && K > 0 && N > 0 && (size_t)N * K + N <= GLINEAR_MAX_FLOATS, "glinear_fwd: bad argument");
+    MEDP_CHECK_ARG(x && W && y && G > 0 && R > 0 && K > 0 && N > 0 && (size_t)N * (K + 1) + N <= GLINEAR_MAX_FLOATS, "glinear_fwd: bad argument");
     MEDP_ONCE_PER_DEVICE({   // the per-pathology heads (256 -> 64) need 64.3 KB of weights in LDS: above the 64-KB default limit
         (void)hipFuncSetAttribute((const void*)glinear_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GLINEAR_MAX_FLOATS * 4);
     });
-    glinear_fwd_kernel<<<dim3((R + 255) / 256, G), 256, ((size_t)N * K + N) * 4, (hipStream_t)stream>>>(x, W, b, y, R, K, N);
+    glinear_fwd_kernel<<<dim3((int)min((size_t)1024, ((size_t)R * N + 255) / 256), G), 256, ((size_t)N * (K + 1) + N) * 4, (hipStream_t)stream>>>(x, W, b, y, R, K, N);
     MEDP_LAUNCH_CHECK("medp_glinear_fwd");
     return 0;
 }
@@ -324,7 +378,7 @@ extern "C" int medp_glinear_bwd(const float* dy, const float* x, const float* W,
         MEDP_ONCE_PER_DEVICE({
             (void)hipFuncSetAttribute((const void*)glinear_bwd_dx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GLINEAR_MAX_FLOATS * 4);
         });
-        glinear_bwd_dx_kernel<<<dim3((R + 255) / 256, G), 256, (size_t)N * K * 4, s>>>(dy, W, dx, R, K, N);
+        glinear_bwd_dx_kernel<<<dim3((int)min((size_t)1024, ((size_t)R * K + 255) / 256), G), 256, (size_t)N * K * 4, s>>>(dy, W, dx, R, K, N);
         MEDP_LAUNCH_CHECK("medp_glinear_bwd(dx)");
     }
     if (dW) {
@@ -332,7 +386,11 @@ extern "C" int medp_glinear_bwd(const float* dy, const float* x, const float* W,
         const int nc = dw_chunks(R), rpc = (R + nc - 1) / nc;
         float* pw = workspace;
         float* pb = workspace + (size_t)G * nc * N * K;
-        glinear_bwd_dw_partial_kernel<<<dim3(nc, G), 256, 0, s>>>(dy, x, pw, pb, R, K, N, rpc);
+        MEDP_CHECK_ARG((size_t)rpc * (N + K) * 4 <= 150 * 1024, "glinear_bwd: rows-per-chunk x (N + K) floats must fit LDS");
+        MEDP_ONCE_PER_DEVICE({
+            (void)hipFuncSetAttribute((const void*)glinear_bwd_dw_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        });
+        glinear_bwd_dw_partial_kernel<<<dim3(nc, G), 256, (size_t)rpc * (N + K) * 4, s>>>(dy, x, pw, pb, R, K, N, rpc);
         MEDP_LAUNCH_CHECK("medp_glinear_bwd(partial)");
         sum_chunks_kernel<<<dim3((N * K + 255) / 256, G), 256, 0, s>>>(pw, dW, nc, N * K);
         sum_chunks_kernel<<<dim3((N + 255) / 256, G), 256, 0, s>>>(pb, db, nc, N);
@@ -340,12 +398,20 @@ extern "C" int medp_glinear_bwd(const float* dy, const float* x, const float* W,
     }
     return 0;
 }
+extern "C" size_t medp_gbn_workspace_bytes(int G, int R, int C) {
+    if (G <= 0 || R <= 0 || C <= 0) return 0;
+    return (size_t)G * gbn_chunks(R) * 2 * C * sizeof(float);
+}
 extern "C" int medp_gbn_fwd(const float* x, const float* w, const float* b, float* running_mean, float* running_var, float* y,
-                            float* save_mean, float* save_var, int G, int R, int C, float eps, float momentum, int batch_stats, void* stream) {
+                            float* save_mean, float* save_var, int G, int R, int C, float eps, float momentum, int batch_stats,
+                            float* workspace, void* stream) {
     MEDP_CHECK_ARG(x && w && b && y && save_mean && save_var && G > 0 && R > 0 && C > 0, "gbn_fwd: bad argument");
     hipStream_t s = (hipStream_t)stream;
     if (batch_stats) {
-        gbn_stats_kernel<<<dim3((C + 63) / 64, G), 256, 0, s>>>(x, save_mean, save_var, R, C);
+        MEDP_CHECK_ARG(workspace, "gbn_fwd: batch statistics need a workspace (medp_gbn_workspace_bytes)");
+        const int nc = gbn_chunks(R);
+        gbn_stats_partial_kernel<<<dim3(nc, G, (C + 63) / 64), 256, 0, s>>>(x, workspace, R, C);
+        gbn_stats_final_kernel<<<(G * C + 255) / 256, 256, 0, s>>>(x, workspace, save_mean, save_var, G, R, C, nc);
         MEDP_LAUNCH_CHECK("medp_gbn_fwd(stats)");
         if (running_mean && running_var) {
             gbn_running_kernel<<<(G * C + 255) / 256, 256, 0, s>>>(save_mean, save_var, running_mean, running_var, G * C, R, momentum);
@@ -361,10 +427,12 @@ extern "C" int medp_gbn_fwd(const float* x, const float* w, const float* b, floa
     return 0;
 }
 extern "C" int medp_gbn_bwd(const float* dy, const float* x, const float* w, const float* save_mean, const float* save_var, float* dx,
-                            float* dw, float* db, int G, int R, int C, float eps, int batch_stats, void* stream) {
-    MEDP_CHECK_ARG(dy && x && w && save_mean && save_var && dx && dw && db && G > 0 && R > 0 && C > 0, "gbn_bwd: bad argument");
+                            float* dw, float* db, int G, int R, int C, float eps, int batch_stats, float* workspace, void* stream) {
+    MEDP_CHECK_ARG(dy && x && w && save_mean && save_var && dx && dw && db && workspace && G > 0 && R > 0 && C > 0, "gbn_bwd: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    gbn_bwd_sums_kernel<<<dim3((C + 63) / 64, G), 256, 0, s>>>(dy, x, save_mean, save_var, db, dw, R, C, eps);
+    const int nc = gbn_chunks(R);
+    gbn_bwd_sums_partial_kernel<<<dim3(nc, G, (C + 63) / 64), 256, 0, s>>>(dy, x, save_mean, save_var, workspace, R, C, eps);
+    gbn_bwd_sums_final_kernel<<<(G * C + 255) / 256, 256, 0, s>>>(workspace, db, dw, G, C, nc);
     MEDP_LAUNCH_CHECK("medp_gbn_bwd(sums)");
     gbn_bwd_dx_kernel<<<grid_for((size_t)G * R * C), 256, 0, s>>>(dy, x, save_mean, save_var, w, db, dw, dx, G, R, C, eps, batch_stats);
     MEDP_LAUNCH_CHECK("medp_gbn_bwd(dx)");
@@ -405,9 +473,9 @@ extern "C" int medp_psi_assemble_fwd(const float* xs_ts, const float* var_out, c
 }
 extern "C" int medp_psi_assemble_bwd(const float* xs_ts, const float* dpsi, float* d_var_out, float* d_tab_out, float* d_special_partial /*[B][2][E]*/,
                                      int B, int T, int V, int E, void* stream) {
-    MEDP_CHECK_ARG(xs_ts && dpsi && d_var_out && d_tab_out && d_special_partial && E > 0 && 3 * E <= 256 && (T + 1) * (V + 1) <= 60000,
+    MEDP_CHECK_ARG(xs_ts && dpsi && d_var_out && d_tab_out && d_special_partial && E > 0 && E % 4 == 0 && 3 * E <= 256,
                    "psi_assemble_bwd: bad argument");
-    psi_assemble_bwd_kernel<<<B, 256, (size_t)(T + 1) * (V + 1), (hipStream_t)stream>>>(xs_ts, dpsi, d_var_out, d_tab_out, d_special_partial, B, T, V, E);
+    psi_assemble_bwd_kernel<<<B, 256, (size_t)(256 / (E / 4)) * 3 * E * sizeof(float), (hipStream_t)stream>>>(xs_ts, dpsi, d_var_out, d_tab_out, d_special_partial, B, T, V, E);
     MEDP_LAUNCH_CHECK("medp_psi_assemble_bwd");
     return 0;
 }

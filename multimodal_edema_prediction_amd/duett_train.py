@@ -72,8 +72,9 @@ class GBatchNormFn(torch.autograd.Function):
         y = torch.empty_like(x)
         sm = torch.empty((G, C), dtype=F32, device=x.device)
         sv = torch.empty((G, C), dtype=F32, device=x.device)
+        ws = torch.empty(lib().medp_gbn_workspace_bytes(G, R, C) // 4, dtype=F32, device=x.device) if batch_stats else None
         check(lib().medp_gbn_fwd(ptr(x), ptr(w), ptr(b), ptr(rmean), ptr(rvar), ptr(y), ptr(sm), ptr(sv), G, R, C, BN_EPS, BN_MOMENTUM,
-                                 int(batch_stats), stream()), "gbn_fwd")
+                                 int(batch_stats), ptr(ws), stream()), "gbn_fwd")
         ctx.save_for_backward(x, w, sm, sv)
         ctx.batch_stats = batch_stats
         return y
@@ -84,8 +85,9 @@ class GBatchNormFn(torch.autograd.Function):
         G, R, C = x.shape
         dyc = dy.contiguous()
         dx, dw, db = torch.empty_like(x), torch.empty_like(w), torch.empty_like(w)
+        ws = torch.empty(lib().medp_gbn_workspace_bytes(G, R, C) // 4, dtype=F32, device=x.device)
         check(lib().medp_gbn_bwd(ptr(dyc), ptr(x), ptr(w), ptr(sm), ptr(sv), ptr(dx), ptr(dw), ptr(db), G, R, C, BN_EPS,
-                                 int(ctx.batch_stats), stream()), "gbn_bwd")
+                                 int(ctx.batch_stats), ptr(ws), stream()), "gbn_bwd")
         return dx, dw, db, None, None, None
 
 
@@ -231,19 +233,22 @@ class SelfAttnQKVFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------------ the composition
 def _bind_stacked_bn(model):
-    """Make the V per-variable BatchNorm running statistics views of two stacked [V, H] buffers so the grouped kernel updates
-    them in place (state_dict keys and values are unchanged; re-bound if .to(device) replaced the buffers)."""
+    """Make the V per-variable BatchNorm running statistics (and batch counters) views of stacked buffers so the grouped kernel
+    updates them in place and ONE add advances all V counters (state_dict keys and values are unchanged; re-bound if
+    .to(device) replaced the buffers)."""
     bns = [m[3].batch_norm for m in model.embedding_layers]
     st = getattr(model, "_bn_stack", None)
     ok = st is not None and all(bn.running_mean.data_ptr() == st[0][i].data_ptr() and bn.running_var.data_ptr() == st[1][i].data_ptr()
-                                for i, bn in enumerate(bns))
+                                and bn.num_batches_tracked.data_ptr() == st[2][i].data_ptr() for i, bn in enumerate(bns))
     if not ok:
         rm = torch.stack([bn.running_mean.detach() for bn in bns]).contiguous()
         rv = torch.stack([bn.running_var.detach() for bn in bns]).contiguous()
+        nb = torch.stack([bn.num_batches_tracked.detach() for bn in bns]).contiguous()
         for i, bn in enumerate(bns):
             bn.running_mean = rm[i]
             bn.running_var = rv[i]
-        model._bn_stack = (rm, rv)
+            bn.num_batches_tracked = nb[i]
+        model._bn_stack = (rm, rv, nb)
     return model._bn_stack
 
 
@@ -285,7 +290,7 @@ def encode_training(model, x):
         raise ValueError(f"this backbone was built for n_timesteps={model.masked_transform_timesteps}, got T={T}")
     bs = bool(model.training)                                           # BatchNorm: batch statistics in train(), running in eval()
     el = model.embedding_layers
-    rm, rv = _bind_stacked_bn(model)
+    rm, rv, nbt = _bind_stacked_bn(model)
     # per-variable MLPs as ONE grouped pass (group = variable)                                  (model :45-55)
     xin = EmbedInputsFn.apply(xs_feats, model.n_obs_embedding.weight)
     var_out = _mlp_bn(xin, torch.stack([m[0].weight for m in el]), torch.stack([m[0].bias for m in el]),
@@ -311,8 +316,9 @@ def encode_training(model, x):
     time_emb = torch.cat([temb, model.full_rep_embedding.weight.T.unsqueeze(0).expand(B, -1, -1)], 1)     # [B, T+1, tt]
     if bs:
         with torch.no_grad():
-            for bn in [m[3].batch_norm for m in el] + [tbn, mbn]:
-                bn.num_batches_tracked += 1
+            nbt += 1                                      # all V per-variable counters at once (views of one stacked buffer)
+            tbn.num_batches_tracked += 1
+            mbn.num_batches_tracked += 1
     seed = A.next_seed() if (model.training and model.transformer_dropout > 0) else 0
     T1, V1 = T + 1, V + 1
     for l, (ev, tv) in enumerate(zip(model.event_transformers, model.time_transformers)):
