@@ -1,7 +1,7 @@
 """BASELINE metric, second half: "AUROC parity vs CPU ref" — the experiment SURVEY.md §8(d) / BASELINE.md §3 define: the same
 teacher (same weights) is TRAINED for 200 identical steps (dropout / augmentation off) on a learnable synthetic cohort twice —
 by the HIP engine step (bf16 MFMA operands, fused AdamW) and by the fp32 CPU oracle step — and both models then score the same
-512 held-out items.  Contract tolerances, asserted as written there: per-label AUROC within 0.005, macro AUROC within 0.003.
+1536 held-out items.  Contract tolerances, asserted as written there: per-label AUROC within 0.005, macro AUROC within 0.003.
 The frozen encoders' tokens of the oracle side are computed ONCE per batch on the CPU (by the oracle's own encoders) and reused
 over the 200 steps — they do not change — and the images are 112x112 (65 ViT tokens) so that the CPU side stays in budget."""
 import os
@@ -110,11 +110,13 @@ def test_trained_teacher_auroc_matches_cpu_oracle():
     # lr / pool from tools/auroc_sweep.py (gpurun_out/r2_auroc_sweep.log): at 5e-5 over 512 training items the two runs stay one
     # trajectory (max per-label difference 0.0009); at 5e-4 over 256 items the run memorises the pool, AdamW amplifies bf16
     # rounding into different minima and the held-out AUROCs of BOTH runs are noise around 0.5 (differences up to 0.47)
-    r = run_parity(lr=5e-5, n_steps=200, n_train_b=32, n_eval_b=32)          # 512 training items, 512 held-out items
+    # 1536 held-out items (the contract asks for >= 512): at the cohort's 2 % prevalences 512 items hold one or two positives of
+    # the rare labels, an AUROC that moves by 0.002 per rank of a single item — noise, not parity
+    r = run_parity(lr=5e-5, n_steps=200, n_train_b=32, n_eval_b=96)          # 512 training items, 1536 held-out items
     hl, rl, a_hip, a_ref = r["hip_losses"], r["ref_losses"], r["a_hip"], r["a_ref"]
     print("per-label AUROC hip", np.round(a_hip, 4), "oracle", np.round(a_ref, 4), "max |logit diff|",
           float(np.abs(r["hip_logits"] - r["ref_logits"]).max()), "loss first/last", rl[:3], rl[-3:])
-    assert len(a_hip) == r["K"] and r["n_eval"] == 512
+    assert len(a_hip) == r["K"] and r["n_eval"] == 1536
     assert np.mean(rl[-16:]) < 0.9 * np.mean(rl[:16])                     # a real training run, not a flat line
     np.testing.assert_allclose(hl, rl, rtol=3e-2, atol=2e-2)                 # one trajectory, all 200 steps
     corr = float(np.corrcoef(r["hip_logits"].ravel(), r["ref_logits"].ravel())[0, 1])
