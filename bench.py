@@ -336,7 +336,33 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         torch.distributed.init_process_group("nccl", rank=0, world_size=1)
     reducer = None
-    if args.eager or cfg == "probe":
+    want_graph = not (args.eager or cfg == "probe")
+    graph_error = None
+    if want_graph:
+        from multimodal_edema_prediction_amd.graph_step import GraphedStudentStep, GraphedTeacherStep
+        arm = lambda: abi.check(L.medp_gemm_profile_enable(2), "gemm_profile_enable")     # launch clocks ride in the captured GEMMs
+        try:
+            if cfg == "teacher":
+                gstep = GraphedTeacherStep(teacher, loss_fn, opt, dev_pool[0], device, world=world, split=force_pg, pipeline_cxr=pipeline,
+                                           before_capture=arm)
+            else:
+                gstep = GraphedStudentStep(student, teacher, loss_fn, opt, dev_pool[0], device, world=world, split=force_pg,
+                                           pipeline_teacher=pipeline, before_capture=arm)
+            gstep.force_collective = force_pg
+        except Exception as e:                                 # never seen on one GPU; N > 1 has not run on hardware before the driver's run
+            import traceback
+            graph_error = f"{type(e).__name__}: {e}"
+            print(f"[bench rank {rank}] captured-graph step failed to build, falling back to the eager engine step:\n" + traceback.format_exc(),
+                  file=sys.stderr, flush=True)
+            gstep = None
+        L.medp_gemm_profile_enable(0)
+        if world > 1:                                          # every rank takes the same path: fall back everywhere if any rank failed
+            okt = torch.tensor([0 if gstep is None else 1], device=device)
+            torch.distributed.all_reduce(okt, op=torch.distributed.ReduceOp.MIN)
+            if int(okt.item()) == 0:
+                gstep = None
+                graph_error = graph_error or "another rank failed to build the captured step"
+    if gstep is None:
         if world > 1:
             reducer = dp.GradAllReducer([p for p in trainable.parameters() if p.requires_grad]).attach(opt)
 
@@ -362,17 +388,6 @@ def main():
                 sched.step()
             return out
     else:
-        from multimodal_edema_prediction_amd.graph_step import GraphedStudentStep, GraphedTeacherStep
-        arm = lambda: abi.check(L.medp_gemm_profile_enable(2), "gemm_profile_enable")     # launch clocks ride in the captured GEMMs
-        if cfg == "teacher":
-            gstep = GraphedTeacherStep(teacher, loss_fn, opt, dev_pool[0], device, world=world, split=force_pg, pipeline_cxr=pipeline,
-                                       before_capture=arm)
-        else:
-            gstep = GraphedStudentStep(student, teacher, loss_fn, opt, dev_pool[0], device, world=world, split=force_pg,
-                                       pipeline_teacher=pipeline, before_capture=arm)
-        L.medp_gemm_profile_enable(0)
-        gstep.force_collective = force_pg
-
         # One host read of the loss per step, like the reference's per-step logging — of the PREVIOUS step: the loss is copied
         # to pinned memory behind an event, so the host enqueues replay k+1 while the GPU still runs replay k instead of
         # idling the GPU for a launch latency every step.  Every step still runs to completion inside the timed region.
@@ -484,7 +499,7 @@ def main():
         workload = "SIDE MEASUREMENT (--unfreeze_cxr, SURVEY 8f1): " + workload + ", CXR encoder TRAINED as well, no encoder pipelining"
     if side and not (args.stress or args.unfreeze_cxr):
         workload = "SIDE MEASUREMENT (" + ", ".join(f for f, on in (("--resident", args.resident), ("--eager", args.eager), ("--no-pipeline", args.no_pipeline)) if on) + "): " + workload
-    execution = "eager (engine.py from Python)" if (args.eager or cfg == "probe") else (
+    execution = ("eager (engine.py from Python)" + (f" — FALLBACK, the captured step failed to build: {graph_error}" if graph_error else "")) if gstep is None else (
         ("captured HIP graph replay (graph_step.py)" + (": frozen part of batch k+1 run beside the step of batch k (one frozen forward, one "
          "trainable fwd/bwd and one update per replay; 4 distinct batches rotate)" if pipeline else ", frozen part inside its own step"))
         + ("; N>1: fwd/bwd graph -> RCCL mean all-reduce of the flat gradient arena -> optimiser graph on the main stream, the frozen-forward "
