@@ -313,7 +313,7 @@ def encode_training(model, x):
     w3_p = torch.cat([tm[3].weight, tm[3].weight.new_zeros(tm[3].weight.shape[0], pad)], 1) if pad else tm[3].weight
     tt = E * (V + 1)
     temb = A.linear(hb_p, w3_p, tm[3].bias).view(B, T, tt)
-    time_emb = torch.cat([temb, model.full_rep_embedding.weight.T.unsqueeze(0).expand(B, -1, -1)], 1)     # [B, T+1, tt]
+    time_emb = torch.cat([temb, model.full_rep_embedding.weight.view(1, 1, -1).expand(B, -1, -1)], 1)     # [B, T+1, tt]
     if bs:
         with torch.no_grad():
             nbt += 1                                      # all V per-variable counters at once (views of one stacked buffer)

@@ -111,12 +111,15 @@ def test_student_cfg4_shapes_full_size_against_oracle():
     assert float((z32 - zr.detach()).abs().max()) <= 1e-4                        # fp32 kernel mode at the headline size
     assert abs(l32 - float(Lr["total"])) <= 1e-5 * abs(float(Lr["total"]))
     n = 0
+    gmax = max(float(r.grad.abs().max()) for r in ref_sd.values() if torch.is_tensor(r) and r.requires_grad and r.grad is not None)
     for k, r in ref_sd.items():
         if not (torch.is_tensor(r) and r.requires_grad) or r.grad is None:
             continue
         c, ratio = _cos(g16[k], r.grad)
         assert c > 0.99 and abs(ratio - 1) < 0.1, ("bf16", k, c, ratio)
+        # element-wise: 5e-4 of the tensor's largest element, with the fp32 summation floor of a 6144-row reduction (relative to the
+        # model's largest gradient element) under it
         err, scale = float((g32[k].double() - r.grad.double()).abs().max()), float(r.grad.abs().max())
-        assert err <= 5e-4 * scale + 1e-7, ("fp32", k, err, scale)
+        assert err <= 5e-4 * scale + 2e-6 * gmax, ("fp32", k, err, scale, gmax)
         n += 1
     assert n > 100
