@@ -21,6 +21,8 @@
 
 #include <vector>
 
+#include <algorithm>
+
 #include "common.h"
 #include "gemm_variants.h"
 #include "medp_hip.h"
@@ -593,6 +595,19 @@ extern "C" int medp_gemm_profile_collect(double* total_ms, long long* n_launches
     return 0;
 }
 
+// Debug hook (NOT part of the C ABI in include/medp_hip.h; tools/time_branches.py): the raw mode-2 stamps, slot i ->
+// out[2 i] = first workgroup in, out[2 i + 1] = last workgroup out (ticks of the wall clock, *khz per ms), in launch order.
+extern "C" int medp_dbg_gemm_profile_raw(unsigned long long* out, int max_slots, int* n_slots, int* khz) {
+    const int n = (int)std::min(g_prof.slot_flops.size(), (size_t)std::max(max_slots, 0));
+    std::vector<unsigned long long> h((size_t)n * 4);
+    if (n > 0 && hipMemcpy(h.data(), g_prof.slots, (size_t)n * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    for (int i = 0; i < n; ++i) { out[2 * i] = h[4 * i]; out[2 * i + 1] = h[4 * i + 1]; }
+    *n_slots = n;
+    *khz = 100000;
+    (void)hipDeviceGetAttribute(khz, hipDeviceAttributeWallClockRate, g_prof.slot_dev);
+    return 0;
+}
+
 // Split-K plan for SMALL grids (DuETT's skinny GEMMs: M = 3136 / 6208 rows, N = 72 / 512, K = 1176 / 2328 give 25-100 tiles
 // on 256 CUs with a 73-step K-loop each): K is cut into S slices so that tiles x S fills the chip; S = 1: no split.
 static int splitk_slices(int M, int N, int K) {
@@ -650,7 +665,7 @@ int medp_gemm_bf16_nt_tagged_ws(int tag, const void* A, const void* W, void* C, 
     static const int v3_min_tiles = [] { const char* e = getenv("MEDP_GEMM_V3_MIN_TILES"); return e ? atoi(e) : 192; }();
     const int tiles_v3 = ((M + 255) / 256) * ((N + 127) / 128);
     const bool use_v3 = force == 3 || (force == 0 && M >= 2048 && N >= 256 && tiles_v3 >= v3_min_tiles);
-    MedpGemmArgs a4{A, W, C, M, N, K, lda, ldw, ldc, bias, scale, residual, ldr, act, out_bf16, nullptr};
+    MedpGemmArgs a4{A, W, C, M, N, K, lda, ldw, ldc, bias, scale, residual, ldr, act, out_bf16, nullptr, 0};
     if (N <= 64) return launch<128, 64, 0>(p, s);
     // v6 (256 x 256 x 64, 8 waves ping-pong, gemm_bf16_v6.hip) runs ONE workgroup per CU: default once there are enough
     // 256^2 tiles to occupy most of the chip (the CXR-encoder shapes: 195 / 585 / 780 tiles); v3 keeps the smaller grids
@@ -659,7 +674,26 @@ int medp_gemm_bf16_nt_tagged_ws(int tag, const void* A, const void* W, void* C, 
     // v7: the same K-loop, persistent over the tile list, where the grid is more than one round of workgroups (qkv, fc1)
     static const int v7_on = [] { const char* e = getenv("MEDP_GEMM_V7"); return e ? atoi(e) : 1; }();
     const bool use_v7 = use_v6 && force != 6 && v7_on && medp_gemm_v7_eligible(a4);
+    // The ragged last rows (M = 64 * 257: 64 rows past the last full 256-row tile) go to a skinny launch of their own where that
+    // saves the persistent kernel a round of workgroups (fc1: 780 tiles = 4 rounds on 256 CUs, 768 = 3; qkv: 585 and 576 are both
+    // 3 rounds and stay one launch).  Same bits either way (gemm_ragged_rows.hip).  MEDP_GEMM_RAGGED=0: never.
+    static const int ragged_on = [] { const char* e = getenv("MEDP_GEMM_RAGGED"); return e ? atoi(e) : 1; }();
+    const int rag_rows = M % 256, tiles_n256 = (N + 255) / 256, nfull256 = (M / 256) * tiles_n256;
+    const bool split_ragged = use_v7 && ragged_on && rag_rows > 0 && rag_rows <= 128 && nfull256 > 256 &&
+                              (nfull256 + tiles_n256 + 255) / 256 > (nfull256 + 255) / 256;
     auto launch_v67 = [&](int tg) {
+        if (split_ragged) {
+            MedpGemmArgs ar = a4, am = a4;
+            ar.prof_flags = 2;                 // one clock over both launches: the skinny one stamps the arrival ...
+            am.prof_flags = 1;                 // ... the tile kernel the departure
+            am.M = M - rag_rows;
+            if (medp_gemm_v7_eligible(am)) {
+                int rc = medp_gemm_ragged_rows_launch(ar, M - rag_rows, stream);
+                if (rc != 0) return rc;
+                rc = medp_gemm_v7_launch(am, tg, stream);
+                return rc != -1 ? rc : medp_gemm_v6_launch(am, tg, stream);
+            }
+        }
         if (use_v7) {
             const int rc = medp_gemm_v7_launch(a4, tg, stream);
             if (rc != -1) return rc;

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v6_kernel(const MedpGemmA
     const bf16_t* A = (const bf16_t*)p.A;
     const bf16_t* W = (const bf16_t*)p.W;
     const bf16_t* zero = (const bf16_t*)g_zero16_v6;
-    MEDP_PROF_ENTER(p.prof);
+    MEDP_PROF_ENTER(p.prof, p.prof_flags);
 
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int bid = blockIdx.x;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v6_kernel(const MedpGemmA
         }
         MEDP_WAVE_LDS_SYNC();
     }
-    MEDP_PROF_LEAVE(p.prof);
+    MEDP_PROF_LEAVE(p.prof, p.prof_flags);
 }
 
 template <int TAG>

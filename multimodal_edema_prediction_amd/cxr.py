@@ -89,7 +89,7 @@ class Dinov2Backbone(nn.Module):
             _set_param(self, k, nn.Parameter(v))
         self._prep = None
         self._prep_key = None
-        self._ws = None
+        self._ws = {}
 
     @property
     def config(self):
@@ -146,10 +146,12 @@ class Dinov2Backbone(nn.Module):
         self._prep, self._prep_key = (w, layers, keep), key
         return self._prep
 
-    def forward(self, pixel_values: torch.Tensor, want_f32: bool = True, want_bf16: bool = False, layers=None):
+    def forward(self, pixel_values: torch.Tensor, want_f32: bool = True, want_bf16: bool = False, layers=None, slot: int = 0, out16=None):
         """pixel_values fp32 [B,3,H,W] -> last_hidden_state after the final LayerNorm ([B, P+1, hidden]).
         `layers=(first, last)` (frozen path only): run that piece of the encoder (medp_vit_forward_part); the outputs exist
-        only for the piece that ends at the last layer, the token stream waits in this module's workspace in between."""
+        only for the piece that ends at the last layer, the token stream waits in this module's workspace in between.
+        `slot`: which of this module's workspaces to use — concurrent forwards on different streams (sub-batches of one step,
+        graph_step.GraphedTeacherStep) need one each; `out16`: a preallocated bf16 [B, P+1, hidden] destination."""
         abi.require_gpu()
         if pixel_values.dim() != 4 or pixel_values.shape[1] != self.cfg.num_channels:
             raise ValueError("Make sure that the channel dimension of the pixel values match with the one set in the "
@@ -157,6 +159,8 @@ class Dinov2Backbone(nn.Module):
         if any(p.requires_grad for p in self.parameters()) and torch.is_grad_enabled():
             # --unfreeze_cxr: the forward is composed of autograd nodes over the same kernels (cxr_train.py)
             from .cxr_train import forward_training
+            if out16 is not None:
+                raise ValueError("out16 is a frozen-path argument (the training path returns fp32 tokens with a gradient)")
             tok = forward_training(self, pixel_values)
             return (tok if want_f32 else None), (tok if want_bf16 else None)       # fp32 either way: it carries the gradient
         w, _, _ = self._prepare()
@@ -164,14 +168,19 @@ class Dinov2Backbone(nn.Module):
         B, _, H, W = px.shape
         P = (H // self.cfg.patch_size) * (W // self.cfg.patch_size)
         need = lib().medp_vit_workspace_bytes(ctypes.byref(w), B, H, W)
-        if self._ws is None or self._ws.numel() < need or self._ws.device != px.device:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=px.device)
+        ws = self._ws.get(slot)
+        if ws is None or ws.numel() < need or ws.device != px.device:
+            ws = self._ws[slot] = torch.empty(need, dtype=torch.uint8, device=px.device)
         D = self.cfg.hidden_size
         first, last = (0, self.cfg.num_hidden_layers) if layers is None else layers
         fin = last == self.cfg.num_hidden_layers
         out32 = torch.empty((B, P + 1, D), dtype=torch.float32, device=px.device) if (want_f32 and fin) else None
-        out16 = torch.empty((B, P + 1, D), dtype=torch.bfloat16, device=px.device) if (want_bf16 and fin) else None
-        check(lib().medp_vit_forward_part(ctypes.byref(w), ptr(px), B, H, W, ptr(out32), ptr(out16), ptr(self._ws), need, first, last,
+        if out16 is not None:
+            if out16.shape != (B, P + 1, D) or out16.dtype != torch.bfloat16 or not out16.is_contiguous() or out16.device != px.device:
+                raise ValueError("out16 must be a contiguous bf16 [B, P+1, hidden] tensor on the input's device")
+        else:
+            out16 = torch.empty((B, P + 1, D), dtype=torch.bfloat16, device=px.device) if (want_bf16 and fin) else None
+        check(lib().medp_vit_forward_part(ctypes.byref(w), ptr(px), B, H, W, ptr(out32), ptr(out16), ptr(ws), need, first, last,
                                           stream()), "vit_forward")
         return out32, out16
 
@@ -220,10 +229,10 @@ class CXREncoder(nn.Module):
             return cls, tokens[:, 1:]
         return cls
 
-    def forward_bf16(self, pixel_values: torch.Tensor):
+    def forward_bf16(self, pixel_values: torch.Tensor, slot: int = 0, out=None):
         """Build-internal fast path: tokens as bf16 [B, P+1, D], directly consumable by the img_proj GEMM (fp32 tokens with a
-        gradient when the encoder is being trained)."""
-        _, t16 = self.backbone(pixel_values, want_f32=False, want_bf16=True)
+        gradient when the encoder is being trained).  `slot` / `out`: see Dinov2Backbone.forward."""
+        _, t16 = self.backbone(pixel_values, want_f32=False, want_bf16=True, slot=slot, out16=out)
         return t16
 
     def forward_bf16_part(self, pixel_values: torch.Tensor, first: int, last: int):

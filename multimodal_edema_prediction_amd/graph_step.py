@@ -56,7 +56,9 @@ class _GraphedStep:
         self.arena = None
         self.force_collective = False      # bench.py MEDP_FORCE_PG=1: really call RCCL on a size-1 group (one-GPU rehearsal of N > 1)
         self._captured = False
-        self.frozen_stream = torch.cuda.Stream(device=device) if self.pipeline else None
+        # the frozen forward may itself be cut into sub-batches on sibling streams (`_n_frozen_parts`): every one is forked from
+        # the step's own stream — a fork nested inside a forked branch crashes hipStreamEndCapture on this runtime
+        self.frozen_streams = [torch.cuda.Stream(device=device) for _ in range(self._n_frozen_parts())] if self.pipeline else []
         # warm-up on a side stream (allocator pools, lazy workspaces, optimiser state), as torch.cuda.graphs requires
         s = torch.cuda.Stream(device=device)
         s.wait_stream(torch.cuda.current_stream(device))
@@ -87,8 +89,7 @@ class _GraphedStep:
         if not self.split:
             with torch.cuda.graph(self.g_fb):
                 self._advance()
-                self.out = self._whole_fwd_bwd()
-                self.opt.step()
+                self.out = self._whole_fwd_bwd(then=self.opt.step)
         else:
             with torch.cuda.graph(self.g_fb):
                 self.arena.flat.zero_()
@@ -119,18 +120,30 @@ class _GraphedStep:
         if self.arena is not None and (self.world > 1 or self.force_collective):
             self.arena.all_reduce(force=self.force_collective)
 
-    def _whole_fwd_bwd(self):
-        """One-stream-of-control form: the frozen forward of the next batch as a parallel branch inside the same capture."""
+    def _whole_fwd_bwd(self, then=None):
+        """One-stream-of-control form: the frozen forward of the next batch as a parallel branch inside the same capture.
+        `then` (the optimiser update of the one-graph step) runs behind the backward and BEFORE the join: it depends on nothing
+        the frozen branch produces, so it hides under that branch's tail instead of extending the step."""
         if not self.pipeline:
-            return self._train_fwd_bwd()
+            out = self._train_fwd_bwd()
+            if then is not None:
+                then()
+            return out
         cur = torch.cuda.current_stream(self.device)
-        self.frozen_stream.wait_stream(cur)
-        with torch.cuda.stream(self.frozen_stream):
-            self._frozen_forward()
+        for part, fs in enumerate(self.frozen_streams):
+            fs.wait_stream(cur)
+            with torch.cuda.stream(fs):
+                self._frozen_forward(part)
         out = self._train_fwd_bwd()
-        cur.wait_stream(self.frozen_stream)
+        if then is not None:
+            then()
+        for fs in self.frozen_streams:
+            cur.wait_stream(fs)
         self._hand_over()
         return out
+
+    def _n_frozen_parts(self) -> int:
+        return 1
 
     def _replay(self):
         """refresh_lrs + the graph(s) of one step on the current stream."""
@@ -164,7 +177,10 @@ class GraphedTeacherStep(_GraphedStep):
             self.pixels_next = self.pixels.clone()
             with torch.no_grad():
                 self.tok_cur = teacher.cxr.forward_bf16(self.pixels).clone()
-            self.tok_next = None
+            self.tok_next = torch.empty_like(self.tok_cur)
+            # sub-batches of the frozen encoder on sibling streams: the hardware dispatcher then fills the CUs one sub-batch's GEMM
+            # leaves idle in its last round of tiles with the other's kernels (MEDP_CXR_PARTS; measured SLOWER on MI355X — 5.83 ms with 2 parts, 7.26 ms with 4 against 5.30 ms — so the default is 1)
+            self.cxr_parts = max(1, min(int(os.environ.get("MEDP_CXR_PARTS", "1")), self.pixels.shape[0]))
             self._expect = None        # id() of the batch whose tokens sit in tok_cur
         self.y_multi = b["y_multi"].clone().float()
         self.y_mask = b["y_multi_mask"].clone().float()
@@ -172,16 +188,19 @@ class GraphedTeacherStep(_GraphedStep):
         self._setup(optimizer, device, world, group, split, pipeline_cxr, warmup, before_capture)
 
     # ---- the three pieces of a step ----------------------------------------------------------------------------------------
-    def _frozen_forward(self):
-        with torch.no_grad():
-            self.tok_next = self.teacher.cxr.forward_bf16(self.pixels_next)      # batch k+1, beside batch k's step
+    def _n_frozen_parts(self) -> int:
+        return self.cxr_parts
+
+    def _frozen_forward(self, part: int = 0):
+        B, n = self.pixels_next.shape[0], self.cxr_parts
+        lo, hi = part * B // n, (part + 1) * B // n
+        with torch.no_grad():                                                    # batch k+1, beside batch k's step
+            self.teacher.cxr.forward_bf16(self.pixels_next[lo:hi], slot=part, out=self.tok_next[lo:hi])
 
     def _stateful_modules(self):
         return [self.teacher]
 
     def _hand_over(self):
-        if not self._captured:             # graph-pool tensors live as long as their graph: nothing to tell the allocator later
-            self.tok_next.record_stream(torch.cuda.current_stream(self.device))
         self.tok_cur.copy_(self.tok_next)      # after the backward: the weight-gradient GEMM of img_proj reads tok_cur
 
     def _train_fwd_bwd(self):
@@ -301,7 +320,7 @@ class GraphedStudentStep(_GraphedStep):
         return self.teacher(tuple(bufs["x_ts"][i] for i in range(B)), tuple(bufs["x_static"][i] for i in range(B)),
                             tuple(bufs["bin_ends"][i] for i in range(B)), bufs["pixel_values"], **kw)["main_logit"]
 
-    def _frozen_forward(self):
+    def _frozen_forward(self, part: int = 0):
         # this forward IS a forked branch of the capture: it must not fork again (nested forks crash hipStreamEndCapture here)
         with torch.no_grad():
             self.z_next = self._teacher_logit(self.nxt, forked=True)

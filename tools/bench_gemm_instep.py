@@ -8,7 +8,7 @@ import torch
 from multimodal_edema_prediction_amd import functional as Fn
 
 dev = "cuda"
-M, D, F = 64 * 257, 768, 3072
+M, D, F = int(os.environ.get("M", 64 * 257)), 768, 3072
 R = int(os.environ.get("ROT", "4"))
 def mk(*shape, dtype=torch.bfloat16): return [torch.randn(*shape, device=dev).to(dtype) for _ in range(R)]
 cases = {
