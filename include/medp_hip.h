@@ -62,6 +62,13 @@ int medp_gemm_f32_tn(const float* dY, const float* X, float* C, int M, int N, in
 size_t medp_gemm_tn_workspace_bytes(int M, int N, int K);
 int medp_gemm_bf16_tn(const void* dY, const void* X, float* C, int M, int N, int K, int lddy, int ldx, float* workspace, void* stream);
 
+/* How many CUs the persistent 256 x 256 GEMM (multi-round grids: the CXR encoder's qkv / fc1) may hold for a whole launch:
+ * launches issued or CAPTURED from now on start at most `cap` workgroups (a multiple of 8 in 8..256 is used; 0 = the default,
+ * 256 or MEDP_V7_WGS) and, below the cap, the fewest that still finish in the same number of rounds.  A step whose OTHER branch
+ * is the long one (graph_step.GraphedStudentStep: the student's DuETT forward/backward beside the frozen teacher) leaves it
+ * more of the chip this way.  Returns the previous cap. */
+int medp_gemm_persistent_cap(int cap);
+
 /* Live timing of the step's dominant kernel (the CXR-encoder block GEMMs launched by medp_vit_forward), bench.py's roofline
  * leg.  mode 1: HIP events bracket every such launch on its own stream (eager launches).  mode 2: every such launch issued
  * or CAPTURED while the mode is on carries an in-kernel launch clock (first workgroup in / last workgroup out stamp the

@@ -61,6 +61,7 @@ SIGNATURES = {
     "medp_gemm_f32_tn": (I, [P, P, P, I, I, I, I, I, P]),
     "medp_gemm_tn_workspace_bytes": (SZ, [I, I, I]),
     "medp_gemm_bf16_tn": (I, [P, P, P, I, I, I, I, I, P, P]),
+    "medp_gemm_persistent_cap": (I, [I]),
     "medp_gemm_profile_enable": (I, [I]),
     "medp_gemm_profile_collect": (I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_longlong), ctypes.POINTER(ctypes.c_double)]),
     "medp_attn_fwd_dh64": (I, [P, P, P, P, I, I, I, I, I, I, I, F, P]),

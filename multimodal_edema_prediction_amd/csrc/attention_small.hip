@@ -6,6 +6,8 @@
 // reductions), head-dim on lanes for PV.  Backward recomputes the probabilities, writes dQ per query and
 // accumulates dK/dV in the block's own (batch, head) slice — no cross-block atomics, bitwise reproducible.
 // Dropout on the probabilities uses the counter hash of common.h, regenerated in backward.
+#include <stdlib.h>
+
 #include "common.h"
 #include "medp_hip.h"
 
@@ -215,6 +217,291 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const SmallAttnPara
     }
 }
 
+// ---- FEW queries over many keys (the perceiver: 7 pathology queries over 256 patches / 96 hours / 7 latents, 4 heads of 64) -----
+// The wave-per-query kernels above walk the keys once per query with one wave: 257 dependent-ish steps for 7 rows of output (40 us
+// forward, 91 us backward for 33 MB of K / V — a tenth of what the bytes cost).  Here a workgroup owns one (batch, head) and a
+// THREAD owns a key: its K (and in the backward its V) row sits in registers, the <= 8 query rows in LDS (broadcast reads), so all
+// scores of a key are 8 x 64 FMAs on one lane; the softmax statistics are two block reductions of 8 values; what needs a sum over
+// KEYS (P V in the forward, dS K in the backward) is a second phase with (16-B column piece, key slice) on the threads — whole
+// 256-B rows per 16 lanes — and a 16-way reduction through LDS.  fp32 throughout; K and V are read once (the backward reads K
+// twice, the second time out of L2), dK / dV rows are written by their key's thread.  Same dropout stream as the kernels above.
+constexpr int FQ = 8;            // most queries
+constexpr int FQ_T = 256;        // threads = keys per chunk
+constexpr int FQ_MAXCH = 4;      // Lk <= 1024
+
+// The compiler would hoist all 8 x 16 broadcast LDS reads of a fully unrolled (d, q) loop nest to the top (512 VGPRs: the backward
+// spilled 8 KB per lane); a compiler + scheduler barrier per d step keeps each step's 8 reads next to their 32 FMAs.
+#define FQ_KEEP_IN_STEP()                    \
+    do {                                     \
+        asm volatile("" ::: "memory");       \
+        __builtin_amdgcn_sched_barrier(0);   \
+    } while (0)
+
+// an LDS address the compiler cannot see through: loads from it can neither be hoisted above this point nor merged with
+// earlier loads of the same bytes (kept in 512 VGPRs from the score phase to the dK phase otherwise)
+__device__ __forceinline__ const float* FQ_OPAQUE(const float* p) {
+    asm volatile("" : "+v"(p));
+    return p;
+}
+
+__device__ __forceinline__ void fq_block_reduce(float (&v)[FQ], float* red, int lane, int wave, bool is_max) {
+#pragma unroll
+    for (int q = 0; q < FQ; ++q) v[q] = is_max ? wave_max(v[q]) : wave_sum(v[q]);
+    __syncthreads();                                   // `red` may still be read from the previous reduction
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < FQ; ++q) red[wave * FQ + q] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < FQ; ++q) {
+        const float a = red[q], b = red[FQ + q], c = red[2 * FQ + q], d = red[3 * FQ + q];
+        v[q] = is_max ? fmaxf(fmaxf(a, b), fmaxf(c, d)) : (a + b) + (c + d);
+    }
+}
+
+// scores of this thread's keys (one per chunk) against all queries; returns the softmax probabilities in pr[ch][q]
+template <int NCH>
+__device__ __forceinline__ void fq_probs(const SmallAttnParams& p, const float* sQ, const float* kbase, float* red, int tid, float (&pr)[NCH][FQ]) {
+    const int lane = tid & 63, wave = tid >> 6;
+    float mx[FQ];
+#pragma unroll
+    for (int q = 0; q < FQ; ++q) mx[q] = -INFINITY;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int j = ch * FQ_T + tid;
+        float s[FQ];
+#pragma unroll
+        for (int q = 0; q < FQ; ++q) s[q] = 0.f;
+        if (j < p.Lk) {
+            const float4* kr = (const float4*)(kbase + (size_t)j * p.ldk);
+            float4 kv[16];
+#pragma unroll
+            for (int d = 0; d < 16; ++d) kv[d] = kr[d];
+#pragma unroll
+            for (int d = 0; d < 16; ++d) {
+                const float* sq = FQ_OPAQUE(sQ + d * 4);
+#pragma unroll
+                for (int q = 0; q < FQ; ++q) {
+                    const float4 x = *(const float4*)(sq + q * 64);
+                    s[q] += (x.x * kv[d].x + x.y * kv[d].y) + (x.z * kv[d].z + x.w * kv[d].w);
+                }
+                FQ_KEEP_IN_STEP();
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < FQ; ++q) {
+            pr[ch][q] = j < p.Lk ? s[q] * p.scale : -INFINITY;
+            mx[q] = fmaxf(mx[q], pr[ch][q]);
+        }
+    }
+    fq_block_reduce(mx, red, lane, wave, true);
+    float sum[FQ];
+#pragma unroll
+    for (int q = 0; q < FQ; ++q) sum[q] = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int q = 0; q < FQ; ++q) {
+            const float e = (ch * FQ_T + tid < p.Lk) ? __expf(pr[ch][q] - mx[q]) : 0.f;
+            pr[ch][q] = e;
+            sum[q] += e;
+        }
+    fq_block_reduce(sum, red, lane, wave, false);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int q = 0; q < FQ; ++q) pr[ch][q] *= 1.0f / sum[q];
+}
+
+// out[q][0..63] = sum_j w[q][j] * rows[j][0..63]: thread = (16-B piece c of the row, key slice ks of 16); partial sums meet in LDS
+__device__ __forceinline__ void fq_weighted_rows(const float* sW, int ldw, const float* rows, size_t ld, int Lk, int Lq, float* sR, int tid,
+                                                 float* out, size_t ldo) {
+    const int c = tid & 15, ks = tid >> 4;
+    float4 acc[FQ];
+#pragma unroll
+    for (int q = 0; q < FQ; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j0 = ks; j0 < Lk; j0 += 16 * 4) {
+        float4 r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = (j0 + 16 * u < Lk) ? *(const float4*)(rows + (size_t)(j0 + 16 * u) * ld + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = min(j0 + 16 * u, Lk - 1);            // (past the end the row is zero)
+#pragma unroll
+            for (int q = 0; q < FQ; ++q) {
+                const float w = sW[q * ldw + j];
+                acc[q].x += w * r[u].x; acc[q].y += w * r[u].y; acc[q].z += w * r[u].z; acc[q].w += w * r[u].w;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < FQ; ++q) *(float4*)(sR + ((ks * FQ + q) * 64 + c * 4)) = acc[q];
+    __syncthreads();
+    for (int t = tid; t < Lq * 64; t += FQ_T) {
+        const int q = t >> 6, d = t & 63;
+        float a = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) a += sR[(k2 * FQ + q) * 64 + d];
+        out[(size_t)q * ldo + d] = a;
+    }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(FQ_T) void attn_fq_fwd_kernel(const SmallAttnParams p, void* __restrict__ o, int ldo, int o_bf16) {
+    extern __shared__ float sm[];
+    float* sQ = sm;                          // [FQ][64]
+    float* red = sQ + FQ * 64;               // [4][FQ]
+    float* sO = red + 4 * FQ;                // [FQ][64] fp32 result before the store
+    float* sR = sO + FQ * 64;                // [16][FQ][64]
+    float* sP = sR + 16 * FQ * 64;           // [FQ][LkP]
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const int LkP = NCH * FQ_T;
+    const float* kbase = p.k + (size_t)b * p.kv_bs + h * 64;
+    const float* vbase = p.v + (size_t)b * p.kv_bs + h * 64;
+    for (int t = tid; t < FQ * 64; t += FQ_T) {
+        const int q = t >> 6, d = t & 63;
+        sQ[t] = q < p.Lq ? p.q[(size_t)b * p.q_bs + (size_t)q * p.ldq + h * 64 + d] : 0.f;
+    }
+    __syncthreads();
+    float pr[NCH][FQ];
+    fq_probs<NCH>(p, sQ, kbase, red, tid, pr);
+    const uint32_t seed = p.drop_p > 0.f ? medp_mix_epoch(p.seed, p.epoch) : 0u;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int j = ch * FQ_T + tid;
+#pragma unroll
+        for (int q = 0; q < FQ; ++q) {
+            float w = pr[ch][q];
+            if (p.drop_p > 0.f && q < p.Lq && j < p.Lk)
+                w *= dropout_scale(seed, p.stream_id, ((uint32_t)(b * p.H + h) * p.Lq + q) * p.Lk + j, p.drop_p, p.inv_keep);
+            sP[q * LkP + j] = (q < p.Lq && j < p.Lk) ? w : 0.f;
+        }
+    }
+    __syncthreads();
+    fq_weighted_rows(sP, LkP, vbase, p.ldv, p.Lk, p.Lq, sR, tid, sO, 64);
+    __syncthreads();
+    for (int t = tid; t < p.Lq * 64; t += FQ_T) {
+        const int q = t >> 6, d = t & 63;
+        const size_t oi = ((size_t)b * p.Lq + q) * ldo + h * 64 + d;
+        if (o_bf16) ((bf16_t*)o)[oi] = f2bf(sO[t]); else ((float*)o)[oi] = sO[t];
+    }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(FQ_T) void attn_fq_bwd_kernel(const SmallAttnParams p, const float* __restrict__ dout, int lddo,
+                                                           float* __restrict__ dq, int lddq, float* __restrict__ dk, int lddk,
+                                                           float* __restrict__ dv, int lddv, long long dkv_bs) {
+    extern __shared__ float sm[];
+    float* sQ = sm;                          // [FQ][64]
+    float* sDO = sQ + FQ * 64;               // [FQ][64]
+    float* red = sDO + FQ * 64;              // [4][FQ]
+    float* sR = red + 4 * FQ;                // [16][FQ][64]
+    float* sS = sR + 16 * FQ * 64;           // [FQ][LkP]  dS * scale
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const int LkP = NCH * FQ_T;
+    const float* kbase = p.k + (size_t)b * p.kv_bs + h * 64;
+    const float* vbase = p.v + (size_t)b * p.kv_bs + h * 64;
+    float* dkbase = dk + (size_t)b * dkv_bs + h * 64;
+    float* dvbase = dv + (size_t)b * dkv_bs + h * 64;
+    for (int t = tid; t < FQ * 64; t += FQ_T) {
+        const int q = t >> 6, d = t & 63;
+        sQ[t] = q < p.Lq ? p.q[(size_t)b * p.q_bs + (size_t)q * p.ldq + h * 64 + d] : 0.f;
+        sDO[t] = q < p.Lq ? dout[((size_t)b * p.Lq + q) * lddo + h * 64 + d] : 0.f;
+    }
+    __syncthreads();
+    float pr[NCH][FQ];
+    fq_probs<NCH>(p, sQ, kbase, red, tid, pr);
+    const uint32_t seed = p.drop_p > 0.f ? medp_mix_epoch(p.seed, p.epoch) : 0u;
+    // dP = <dO, V_j> (times the dropout mask), delta = sum_j P dP, and this key's dV row = sum_q (P mask) dO_q
+    float dp[NCH][FQ], delta[FQ];
+#pragma unroll
+    for (int q = 0; q < FQ; ++q) delta[q] = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int j = ch * FQ_T + tid;
+        const bool live = j < p.Lk;
+        float pm[FQ], a[FQ];
+#pragma unroll
+        for (int q = 0; q < FQ; ++q) {
+            pm[q] = 0.f;                                       // the dropout mask (0 for padding)
+            a[q] = 0.f;
+        }
+        if (live) {                                            // one branch around the whole row: no barrier inside
+            float4 vv[16];
+            const float4* vr = (const float4*)(vbase + (size_t)j * p.ldv);
+#pragma unroll
+            for (int d = 0; d < 16; ++d) vv[d] = vr[d];
+#pragma unroll
+            for (int q = 0; q < FQ; ++q) {
+                float msk = 1.f;
+                if (p.drop_p > 0.f && q < p.Lq)
+                    msk = dropout_scale(seed, p.stream_id, ((uint32_t)(b * p.H + h) * p.Lq + q) * p.Lk + j, p.drop_p, p.inv_keep);
+                pm[q] = q < p.Lq ? msk : 0.f;
+            }
+            float4* dvr = (float4*)(dvbase + (size_t)j * lddv);
+#pragma unroll
+            for (int d = 0; d < 16; ++d) {                     // one pass over dO's 16-B pieces serves dP (dot with V) and dV (sum over q)
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float* sd = FQ_OPAQUE(sDO + d * 4);
+#pragma unroll
+                for (int q = 0; q < FQ; ++q) {
+                    const float4 x = *(const float4*)(sd + q * 64);
+                    a[q] += (x.x * vv[d].x + x.y * vv[d].y) + (x.z * vv[d].z + x.w * vv[d].w);
+                    const float w = pr[ch][q] * pm[q];
+                    acc.x += w * x.x; acc.y += w * x.y; acc.z += w * x.z; acc.w += w * x.w;
+                }
+                dvr[d] = acc;
+                FQ_KEEP_IN_STEP();
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < FQ; ++q) {
+            dp[ch][q] = a[q] * pm[q];
+            delta[q] += pr[ch][q] * dp[ch][q];
+        }
+    }
+    fq_block_reduce(delta, red, lane, wave, false);
+    // dS (times the scale) -> LDS for the dQ phase; this key's dK row = sum_q dS_q Q_q
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int j = ch * FQ_T + tid;
+        const bool live = j < p.Lk;
+        float ds[FQ];
+#pragma unroll
+        for (int q = 0; q < FQ; ++q) {
+            ds[q] = (live && q < p.Lq) ? pr[ch][q] * (dp[ch][q] - delta[q]) * p.scale : 0.f;
+            sS[q * LkP + j] = ds[q];
+        }
+        if (live) {
+            float4* dkr = (float4*)(dkbase + (size_t)j * lddk);
+#pragma unroll
+            for (int d = 0; d < 16; ++d) {
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float* sq = FQ_OPAQUE(sQ + d * 4);
+#pragma unroll
+                for (int q = 0; q < FQ; ++q) {
+                    const float4 x = *(const float4*)(sq + q * 64);
+                    a.x += ds[q] * x.x; a.y += ds[q] * x.y; a.z += ds[q] * x.z; a.w += ds[q] * x.w;
+                }
+                dkr[d] = a;
+                FQ_KEEP_IN_STEP();
+            }
+        }
+    }
+    __syncthreads();
+    fq_weighted_rows(sS, LkP, kbase, p.ldk, p.Lk, p.Lq, sR, tid, dq + (size_t)b * p.Lq * lddq + h * 64, lddq);
+}
+
+// shapes the few-query kernels take: <= 8 queries, head dim 64, <= 1024 keys, 16-B aligned rows
+bool fq_eligible(const SmallAttnParams& p, const void* a, const void* b2, int lda, int ldb) {
+    static const int on = [] { const char* e = getenv("MEDP_ATTN_FEWQ"); return e ? atoi(e) : 1; }();
+    return on && p.Lq <= FQ && p.dh == 64 && p.Lk <= FQ_MAXCH * FQ_T && ((p.ldk | p.ldv | lda | ldb) & 3) == 0 && (p.kv_bs & 3) == 0 &&
+           ((((uintptr_t)p.k | (uintptr_t)p.v | (uintptr_t)a | (uintptr_t)b2) & 15) == 0);
+}
+
 int check(const SmallAttnParams& p) {
     MEDP_CHECK_ARG(p.q && p.k && p.v, "attn_small: null operand");
     MEDP_CHECK_ARG(p.B > 0 && p.Lq > 0 && p.Lk > 0 && p.H > 0 && p.dh > 0, "attn_small: bad shape");
@@ -232,9 +519,24 @@ extern "C" int medp_attn_small_fwd(const float* q, int ldq, long long q_batch_st
     SmallAttnParams p{q, k, v, ldq, ldkv, ldkv, q_batch_stride, kv_batch_stride, B, Lq, Lk, H, dh, scale, dropout_p, 1.0f / (1.0f - dropout_p), seed, stream_id, medp_rng_epoch_ptr()};
     MEDP_TRY(check(p));
     MEDP_CHECK_ARG(o, "attn_small_fwd: null output");
+    hipStream_t st = (hipStream_t)stream;
+    if (!attn_avg && fq_eligible(p, k, v, 4, 4)) {
+        const int nch = (Lk + FQ_T - 1) / FQ_T;
+        const int nchp = nch <= 1 ? 1 : (nch <= 2 ? 2 : 4);
+        const size_t fl = (size_t)(2 * FQ * 64 + 4 * FQ + 16 * FQ * 64 + FQ * nchp * FQ_T) * sizeof(float);
+        MEDP_ONCE_PER_DEVICE({
+            hipFuncSetAttribute((const void*)attn_fq_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            hipFuncSetAttribute((const void*)attn_fq_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            hipFuncSetAttribute((const void*)attn_fq_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        });
+        if (nchp == 1) attn_fq_fwd_kernel<1><<<B * H, FQ_T, fl, st>>>(p, o, ldo, o_bf16);
+        else if (nchp == 2) attn_fq_fwd_kernel<2><<<B * H, FQ_T, fl, st>>>(p, o, ldo, o_bf16);
+        else attn_fq_fwd_kernel<4><<<B * H, FQ_T, fl, st>>>(p, o, ldo, o_bf16);
+        MEDP_LAUNCH_CHECK("medp_attn_small_fwd(few queries)");
+        return 0;
+    }
     const size_t lds = (size_t)(4 * Lk + 4 * dh) * sizeof(float);
     const int nper = (Lk + 63) / 64;
-    hipStream_t st = (hipStream_t)stream;
     const dim3 grid(B * H, (Lq + FWD_QCH - 1) / FWD_QCH);
     if (nper <= 1) attn_small_fwd_kernel<1><<<grid, 256, lds, st>>>(p, o, ldo, o_bf16, attn_avg);
     else if (nper <= 2) attn_small_fwd_kernel<2><<<grid, 256, lds, st>>>(p, o, ldo, o_bf16, attn_avg);
@@ -254,6 +556,22 @@ extern "C" int medp_attn_small_bwd(const float* dout, int lddo, const float* q, 
     SmallAttnParams p{q, k, v, ldq, ldkv, ldkv, q_batch_stride, kv_batch_stride, B, Lq, Lk, H, dh, scale, dropout_p, 1.0f / (1.0f - dropout_p), seed, stream_id, medp_rng_epoch_ptr()};
     MEDP_TRY(check(p));
     MEDP_CHECK_ARG(dout && dq && dk && dv, "attn_small_bwd: null gradient buffer");
+    if (fq_eligible(p, dk, dv, lddk, 4) && (dkv_batch_stride & 3) == 0) {
+        const int nch = (Lk + FQ_T - 1) / FQ_T;
+        const int nchp = nch <= 1 ? 1 : (nch <= 2 ? 2 : 4);
+        const size_t fl = (size_t)(2 * FQ * 64 + 4 * FQ + 16 * FQ * 64 + FQ * nchp * FQ_T) * sizeof(float);
+        MEDP_ONCE_PER_DEVICE({
+            hipFuncSetAttribute((const void*)attn_fq_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            hipFuncSetAttribute((const void*)attn_fq_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            hipFuncSetAttribute((const void*)attn_fq_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        });
+        hipStream_t fs = (hipStream_t)stream;
+        if (nchp == 1) attn_fq_bwd_kernel<1><<<B * H, FQ_T, fl, fs>>>(p, dout, lddo, dq, lddq, dk, lddk, dv, lddv, dkv_batch_stride);
+        else if (nchp == 2) attn_fq_bwd_kernel<2><<<B * H, FQ_T, fl, fs>>>(p, dout, lddo, dq, lddq, dk, lddk, dv, lddv, dkv_batch_stride);
+        else attn_fq_bwd_kernel<4><<<B * H, FQ_T, fl, fs>>>(p, dout, lddo, dq, lddq, dk, lddk, dv, lddv, dkv_batch_stride);
+        MEDP_LAUNCH_CHECK("medp_attn_small_bwd(few queries)");
+        return 0;
+    }
     const size_t lds = (size_t)(2 * QCH * Lk + 2 * QCH * dh) * sizeof(float);
     MEDP_CHECK_ARG(lds <= 160 * 1024, "attn_small_bwd: Lk too large for LDS");
     MEDP_ONCE_PER_DEVICE({

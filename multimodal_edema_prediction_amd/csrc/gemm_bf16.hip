@@ -676,8 +676,10 @@ int medp_gemm_bf16_nt_tagged_ws(int tag, const void* A, const void* W, void* C, 
     const bool use_v7 = use_v6 && force != 6 && v7_on && medp_gemm_v7_eligible(a4);
     // The ragged last rows (M = 64 * 257: 64 rows past the last full 256-row tile) go to a skinny launch of their own where that
     // saves the persistent kernel a round of workgroups (fc1: 780 tiles = 4 rounds on 256 CUs, 768 = 3; qkv: 585 and 576 are both
-    // 3 rounds and stay one launch).  Same bits either way (gemm_ragged_rows.hip).  MEDP_GEMM_RAGGED=0: never.
-    static const int ragged_on = [] { const char* e = getenv("MEDP_GEMM_RAGGED"); return e ? atoi(e) : 1; }();
+    // 3 rounds and stay one launch).  Same bits either way (gemm_ragged_rows.hip).  OFF by default (MEDP_GEMM_RAGGED=1 turns it
+    // on): alone fc1 gains (102 -> 94 us), but inside the teacher step the 3 full rounds take all 256 CUs where the 4 rounds of
+    // 200 workgroups leave 56 to the other branch for the same CU-time — in-box A/B 5.17 ms with, 5.11-5.13 ms without.
+    static const int ragged_on = [] { const char* e = getenv("MEDP_GEMM_RAGGED"); return e ? atoi(e) : 0; }();
     const int rag_rows = M % 256, tiles_n256 = (N + 255) / 256, nfull256 = (M / 256) * tiles_n256;
     const bool split_ragged = use_v7 && ragged_on && rag_rows > 0 && rag_rows <= 128 && nfull256 > 256 &&
                               (nfull256 + tiles_n256 + 255) / 256 > (nfull256 + 255) / 256;

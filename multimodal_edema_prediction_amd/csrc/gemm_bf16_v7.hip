@@ -402,6 +402,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v7_kernel(const MedpGemmA
 }
 
 std::atomic<unsigned> g_ring_next{0}, g_capture_next{0};
+std::atomic<int> g_api_cap{0};           // medp_gemm_persistent_cap: 0 = default
 unsigned long long* g_trace = nullptr;   // debug hook, see medp_dbg_gemm_v7_trace
 
 template <int TAG>
@@ -431,7 +432,9 @@ int launch_v7(const MedpGemmArgs& a, hipStream_t stream) {
     // tiles) and fc1 (780) need 3 and 4 rounds on 256 CUs and equally on 200; the 56 CUs left alone serve the other branches of
     // the step for the whole launch (teacher step 5.39 -> 5.19 ms, and the GEMMs themselves run 4 % faster: fewer L2 clients).
     // MEDP_V7_WGS (a multiple of 8, <= 256) caps the count: the rounds are then counted against the cap.
-    static const int cap = [] { const char* e = getenv("MEDP_V7_WGS"); const int v = e ? atoi(e) : NWG; return (v >= 8 && v <= NWG) ? (v & ~7) : NWG; }();
+    static const int env_cap = [] { const char* e = getenv("MEDP_V7_WGS"); const int v = e ? atoi(e) : NWG; return (v >= 8 && v <= NWG) ? (v & ~7) : NWG; }();
+    const int api_cap = g_api_cap.load();
+    const int cap = api_cap > 0 ? api_cap : env_cap;
     const int ntiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const int rounds = (ntiles + cap - 1) / cap;
     static const int fewest = [] { const char* e = getenv("MEDP_V7_FEWEST_WGS"); return e ? atoi(e) : 1; }();      // 0: always `cap` workgroups (A/B)
@@ -452,6 +455,11 @@ bool medp_gemm_v7_eligible(const MedpGemmArgs& a) {
 // returns -1 when no private ticket block is left (caller launches v6 instead)
 int medp_gemm_v7_launch(const MedpGemmArgs& a, int tag, void* stream) {
     return tag == 1 ? launch_v7<1>(a, (hipStream_t)stream) : launch_v7<0>(a, (hipStream_t)stream);
+}
+
+extern "C" int medp_gemm_persistent_cap(int cap) {
+    const int v = cap <= 0 ? 0 : (cap < 8 ? 8 : (cap > NWG ? NWG : (cap & ~7)));
+    return g_api_cap.exchange(v);
 }
 
 // Debug hook (NOT part of the C ABI in include/medp_hip.h; tools/trace_gemm_v7.py): while `buf` (device memory, 256 x 40 x u64)

@@ -312,7 +312,14 @@ class GraphedStudentStep(_GraphedStep):
             self.z_cur = self._teacher_logit(self.cur).clone()
         self.z_next = None
         self._expect = None
-        self._setup(optimizer, device, world, group, split, pipeline_teacher, warmup, before_capture)
+        self.swap_roles = os.environ.get("MEDP_STUDENT_SWAP", "0") == "1"       # measured slower (9.00 vs 8.74 ms): more concurrency = more CU contention
+        # the student's branch is the long one here: the frozen teacher's persistent GEMMs hold at most 176 CUs per launch
+        # (in-box A/B: 8.70 ms at the default, 8.47 at 176 / 160, 8.99 at 128)
+        prev = lib().medp_gemm_persistent_cap(int(os.environ.get("MEDP_STUDENT_GEMM_CAP", "176")) if pipeline_teacher else 0)
+        try:
+            self._setup(optimizer, device, world, group, split, pipeline_teacher, warmup, before_capture)
+        finally:
+            lib().medp_gemm_persistent_cap(prev)
 
     def _teacher_logit(self, bufs, forked: bool = False):
         B = bufs["x_ts"].shape[0]
@@ -321,9 +328,27 @@ class GraphedStudentStep(_GraphedStep):
                             tuple(bufs["bin_ends"][i] for i in range(B)), bufs["pixel_values"], **kw)["main_logit"]
 
     def _frozen_forward(self, part: int = 0):
-        # this forward IS a forked branch of the capture: it must not fork again (nested forks crash hipStreamEndCapture here)
+        # as a forked branch of the capture this forward must not fork again (nested forks crash hipStreamEndCapture here)
         with torch.no_grad():
-            self.z_next = self._teacher_logit(self.nxt, forked=True)
+            self.z_next = self._teacher_logit(self.nxt, forked=not self.swap_roles)
+
+    def _whole_fwd_bwd(self, then=None):
+        """Roles swapped against the base class: the STUDENT's forward/backward/update is the forked branch and the frozen teacher
+        runs on the step's own stream — there it may fork its time-series half beside its CXR encoder (a sibling of the training
+        branch, not a nested fork), so the frozen branch is max(encoder, DuETT + heads) long instead of their sum."""
+        if not (self.pipeline and self.swap_roles):
+            return super()._whole_fwd_bwd(then)
+        cur = torch.cuda.current_stream(self.device)
+        ts = self.frozen_streams[0]
+        ts.wait_stream(cur)
+        with torch.cuda.stream(ts):
+            out = self._train_fwd_bwd()
+            if then is not None:
+                then()
+        self._frozen_forward()
+        cur.wait_stream(ts)
+        self._hand_over()
+        return out
 
     def _stateful_modules(self):
         return [self.student, self.teacher]

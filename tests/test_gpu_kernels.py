@@ -198,6 +198,35 @@ def test_attn_small_fwd_bwd(B, Lq, Lk, H, dh, p):
     assert_close(dv, vr.grad, 1e-4, 1e-5, "attn_small dv")
 
 
+@pytest.mark.parametrize("B,Lq,Lk", [(3, 7, 256), (2, 7, 97), (2, 7, 7), (2, 8, 1000), (2, 5, 300), (1, 1, 64)])
+def test_attn_few_query_kernels(B, Lq, Lk):
+    """<= 8 queries, head dim 64, <= 1024 keys (the perceiver blocks): the thread-per-key kernels of attention_small.hip, forward
+    and backward against fp64, and — with dropout on — against the wave-per-query forward, which draws the same mask."""
+    H, dh = 4, 64
+    D = H * dh
+    q, k, v, do = rnd(B, Lq, D, seed=1), rnd(B, Lk, D, seed=2), rnd(B, Lk, D, seed=3), rnd(B, Lq, D, seed=4)
+    scale = dh ** -0.5
+    qr, kr, vr = [t.clone().double().requires_grad_(True) for t in (q, k, v)]
+    sp = lambda t, L: t.view(B, L, H, dh).transpose(1, 2)
+    w = torch.softmax(sp(qr, Lq) @ sp(kr, Lk).transpose(-1, -2) * scale, dim=-1)
+    o = (w @ sp(vr, Lk)).transpose(1, 2).reshape(B, Lq, D)
+    o.backward(do.double())
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    got = Fn.attn_small_fwd(qd, kd, vd, B, Lq, Lk, H, dh, scale)                          # no attn_avg: the few-query forward
+    assert_close(got, o, 1e-4, 1e-5, "few-query fwd")
+    dq, dk, dv = Fn.attn_small_bwd(do.to(DEV), qd, kd, vd, B, Lq, Lk, H, dh, scale)
+    assert_close(dq, qr.grad, 1e-4, 1e-5, "few-query dq")
+    assert_close(dk, kr.grad, 1e-4, 1e-5, "few-query dk")
+    assert_close(dv, vr.grad, 1e-4, 1e-5, "few-query dv")
+    args = dict(dropout_p=0.25, seed=77, stream_id=3)
+    o_fq = Fn.attn_small_fwd(qd, kd, vd, B, Lq, Lk, H, dh, scale, **args)
+    o_gen = Fn.attn_small_fwd(qd, kd, vd, B, Lq, Lk, H, dh, scale, attn_avg=torch.zeros(B, Lq, Lk, device=DEV), **args)
+    assert_close(o_fq, o_gen.cpu(), 1e-4, 1e-5, "few-query fwd vs wave-per-query fwd under the same dropout mask")
+    _, _, dv_d = Fn.attn_small_bwd(do.to(DEV), qd, kd, vd, B, Lq, Lk, H, dh, scale, **args)
+    lhs, rhs = float((dv_d.double() * vd.double()).sum()), float((do.to(DEV).double() * o_fq.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(rhs))                                     # backward regenerates the forward's mask
+
+
 def test_attn_small_shared_query_and_strided_kv():
     """Perceiver cross blocks: one [7,256] query shared by the batch (batch stride 0) over keys that skip the CLS row."""
     B, Lq, Lk, H, dh = 3, 7, 16, 4, 64

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """v7 (persistent v6, gemm_bf16_v7.hip) must reproduce v6 BIT FOR BIT (same K order per tile, same epilogue) on every shape it
 is eligible for — eager, repeated (ticket blocks re-arm themselves), on two streams at once, and captured in a graph.
-Runs itself twice (MEDP_GEMM_V7=1 / 0) and compares the output digests; each run also checks against an fp32 product."""
+Runs itself three times (MEDP_GEMM_V7=1 / 0, and 1 with MEDP_GEMM_RAGGED=1: gemm_ragged_rows.hip) and compares the output digests; each run also checks against an fp32 product."""
 import hashlib, json, os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -72,18 +72,20 @@ if __name__ == "__main__":
         child()
         sys.exit(0)
     res = {}
-    for v in ("1", "0"):
-        env = dict(os.environ, MEDP_GEMM_V7=v)
+    # "1": persistent kernel; "0": one tile per workgroup; "ragged": persistent + the ragged last rows as their own skinny launch
+    for v, extra in (("1", {"MEDP_GEMM_V7": "1", "MEDP_GEMM_RAGGED": "0"}), ("0", {"MEDP_GEMM_V7": "0", "MEDP_GEMM_RAGGED": "0"}),
+                     ("ragged", {"MEDP_GEMM_V7": "1", "MEDP_GEMM_RAGGED": "1"})):
+        env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, stdout=subprocess.PIPE, text=True, timeout=900)
         if r.returncode != 0:
-            print(f"MEDP_GEMM_V7={v}: child failed rc={r.returncode}"); sys.exit(1)
+            print(f"{extra}: child failed rc={r.returncode}"); sys.exit(1)
         res[v] = json.loads(r.stdout.strip().splitlines()[-1])
     bad = 0
     for key in res["1"]:
-        a, b = res["1"][key], res["0"][key]
-        same = a["digest"] == b["digest"]
-        good = same and a["ok"] and b["ok"]
+        a, b, c = res["1"][key], res["0"][key], res["ragged"][key]
+        same = a["digest"] == b["digest"] == c["digest"]
+        good = same and a["ok"] and b["ok"] and c["ok"]
         bad += not good
-        print(f"{key:22s} v7==v6 bitwise: {same}   v7 ok: {a['ok']}   v6 ok: {b['ok']}")
+        print(f"{key:22s} v7 == v6 == v7 + ragged-row launch bitwise: {same}   ok: {a['ok']} {b['ok']} {c['ok']}")
     print("FAILED" if bad else "ALL OK")
     sys.exit(1 if bad else 0)

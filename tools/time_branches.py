@@ -13,15 +13,24 @@ from multimodal_edema_prediction_amd.optim import FusedAdamW, make_param_groups
 
 T, V, DS, K, B = 96, 48, 8, 7, 64
 dev = torch.device("cuda", 0)
-teacher = bench.build_teacher(T, V, DS, K, dev)
-loss_fn = DualPathologyLoss(torch.ones(K), None, 0.5, 0.5, 1.0).to(dev)
-opt = FusedAdamW(make_param_groups(teacher, 8e-5), weight_decay=5e-2)
+STUDENT = len(sys.argv) > 1 and sys.argv[1] == "student"
+teacher = bench.build_teacher(T, V, DS, K, dev, freeze_all=STUDENT)
 bt = make_batch(CohortCfg(n_timesteps=T, n_vars=V, d_static=DS, image_size=224, n_labels=K, seed=1234), 0, B, mode="teacher")
+if STUDENT:
+    from multimodal_edema_prediction_amd.graph_step import GraphedStudentStep
+    from multimodal_edema_prediction_amd.losses_duett import StudentKDLoss
+    student = bench.build_student(T, V, DS, dev)
+    loss_fn = StudentKDLoss("vanilla_kl", 4.0, 0.5)
+    opt = FusedAdamW(make_param_groups(student, 8e-5), weight_decay=5e-2)
+else:
+    loss_fn = DualPathologyLoss(torch.ones(K), None, 0.5, 0.5, 1.0).to(dev)
+    opt = FusedAdamW(make_param_groups(teacher, 8e-5), weight_decay=5e-2)
 import ctypes
 from multimodal_edema_prediction_amd import abi
 L = abi.lib()
 L.medp_gemm_profile_enable(2)          # launch clocks ride in every CXR-encoder block GEMM captured from here on
-gs = GraphedTeacherStep(teacher, loss_fn, opt, bt, dev, pipeline_cxr=True)
+gs = (GraphedStudentStep(student, teacher, loss_fn, opt, bt, dev) if STUDENT else
+      GraphedTeacherStep(teacher, loss_fn, opt, bt, dev, pipeline_cxr=True))
 n_step = None
 
 
@@ -73,5 +82,5 @@ torch.cuda.synchronize()
 t_train = replay_ms(g_train.replay)
 t_vit = replay_ms(g_vit.replay)
 timeline("block GEMMs of the encoder alone (last replay)", n_step, 4096)
-print(f"whole step {whole:.3f} ms | training branch alone {t_train:.3f} ms | frozen CXR encoder alone {t_vit:.3f} ms "
+print(f"{'student' if STUDENT else 'teacher'}: whole step {whole:.3f} ms | training branch alone {t_train:.3f} ms | frozen branch alone {t_vit:.3f} ms "
       f"(MEDP_OVERLAP={os.environ.get('MEDP_OVERLAP', 'default')}, MEDP_V7_WGS={os.environ.get('MEDP_V7_WGS', 'auto')})", flush=True)
