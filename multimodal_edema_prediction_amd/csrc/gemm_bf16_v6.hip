@@ -60,7 +60,7 @@ constexpr int LDS_MAIN = 2 * KBUF, LDS_EPI = 8 * 64 * 68 * 4, LDS_BYTES = LDS_EP
     } while (0)
 
 template <int TAG>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v6_kernel(const MedpGemmArgs p) {
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v6_kernel(const MedpGemmArgs p, unsigned* slot) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,7 +72,30 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v6_kernel(const MedpGemmA
     MEDP_PROF_ENTER(p.prof, p.prof_flags);
 
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int bid = blockIdx.x;
+    // Tile index.  Static: workgroup b owns tile b.  With a ticket block (`slot`, one-round grids inside a multi-stream step: proj /
+    // fc2, 195 tiles) MORE workgroups than tiles are launched and each draws its tile from the queue of its XCD (ticket t of XCD x
+    // is tile 8 t + x: the tile the static map gives that XCD's t-th workgroup, so the L2 locality of the map below holds): the
+    // tiles go to whichever CUs are free FIRST, a workgroup that becomes resident late — its CU still held short kernels of the
+    // step's other branch — finds the queue empty and leaves, instead of starting its 30-us tile late.  (An experiment, off by
+    // default: see launch_v6.)
+    int bid = blockIdx.x;
+    if (slot) {
+        const int xcd = blockIdx.x & 7;
+        volatile unsigned* box = (volatile unsigned*)smem;
+        if (tid == 0) box[0] = __hip_atomic_fetch_add(slot + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        bid = 8 * (int)__builtin_amdgcn_readfirstlane(box[0]) + xcd;
+        __syncthreads();                                   // everyone has read the ticket before the first LDS-DMA piece may land on it
+        if (bid >= tiles_m * tiles_n) {
+            if (tid == 0) {                                // the last workgroup to leave re-arms the ticket block (as in gemm_bf16_v7.hip)
+                const unsigned left = __hip_atomic_fetch_add(slot + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (left == gridDim.x - 1)
+                    for (int i = 0; i < 9; ++i) __hip_atomic_store(slot + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            MEDP_PROF_LEAVE(p.prof, p.prof_flags);
+            return;
+        }
+    }
     // Block -> tile.  Workgroups are dispatched in index order, block b to XCD b % 8, one per CU (32 CUs per XCD).  The
     // FULL row-tiles come first: XCD x gets a contiguous run of them (band x super-column order inside, see v3) so its L2 sees
     // few panels; the cheap tiles of a ragged last row (M = 64 * 257: 64 live rows, three quarters of their MFMAs skipped)
@@ -271,6 +294,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v6_kernel(const MedpGemmA
         }
         MEDP_WAVE_LDS_SYNC();
     }
+    if (slot && tid == 0) {
+        const unsigned left = __hip_atomic_fetch_add(slot + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left == gridDim.x - 1)
+            for (int i = 0; i < 9; ++i) __hip_atomic_store(slot + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     MEDP_PROF_LEAVE(p.prof, p.prof_flags);
 }
 
@@ -280,7 +308,13 @@ int launch_v6(const MedpGemmArgs& a, hipStream_t stream) {
     MEDP_ONCE_PER_DEVICE({
         hipFuncSetAttribute((const void*)gemm_bf16_nt_v6_kernel<TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     });
-    gemm_bf16_nt_v6_kernel<TAG><<<tiles, 512, LDS_BYTES, stream>>>(a);
+    // MEDP_V6_TICKETS=1: one-round grids launch 256 workgroups that queue for the tiles (see the kernel).  OFF by default: the
+    // hypothesis it tests — proj / fc2 run 30-40 % slower inside the step because workgroups start late on CUs still holding the
+    // other branch's short kernels — did not hold (in-box A/B: proj 41.9 us static, 44.2 us queued; step 5.03 vs 5.12 ms; alone the
+    // ticket costs 1.2 us): what the other branch takes from these GEMMs is cache and memory bandwidth, not CU slots.
+    static const int tickets_on = [] { const char* e = getenv("MEDP_V6_TICKETS"); return e ? atoi(e) : 0; }();
+    unsigned* slot = (tickets_on && tiles >= 64 && tiles < 256) ? medp_gemm_ticket_block(stream) : nullptr;
+    gemm_bf16_nt_v6_kernel<TAG><<<slot ? 256 : tiles, 512, LDS_BYTES, stream>>>(a, slot);
     MEDP_LAUNCH_CHECK("medp_gemm_bf16_nt(v6)");
     return 0;
 }

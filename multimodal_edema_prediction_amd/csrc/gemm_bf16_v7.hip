@@ -29,7 +29,7 @@ namespace {
 __device__ __attribute__((aligned(16))) uint32_t g_zero16_v7[4] = {0, 0, 0, 0};
 
 constexpr int SLOT_WORDS = 16;                    // 8 per-XCD ticket counters, 1 exit counter, padding (64 B)
-constexpr int RING_SLOTS = 1024, CAPTURE_SLOTS = 3072;
+constexpr int RING_SLOTS = 1024, CAPTURE_SLOTS = 15360;
 __device__ unsigned g_v7_slots[(RING_SLOTS + CAPTURE_SLOTS) * SLOT_WORDS];   // zero at module load, self-resetting
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
@@ -405,29 +405,38 @@ std::atomic<unsigned> g_ring_next{0}, g_capture_next{0};
 std::atomic<int> g_api_cap{0};           // medp_gemm_persistent_cap: 0 = default
 unsigned long long* g_trace = nullptr;   // debug hook, see medp_dbg_gemm_v7_trace
 
-template <int TAG>
-int launch_v7(const MedpGemmArgs& a, hipStream_t stream) {
+// A ticket block nobody else is using while the launch it is handed to runs: launches being CAPTURED (replayed for the life of
+// their graph) never share one, eager launches take the next of a ring.  nullptr: none left (the caller launches without tickets).
+unsigned* ticket_block(hipStream_t stream) {
     static unsigned* slots_of[MEDP_MAX_DEVICES] = {};      // the ticket blocks are a __device__ symbol: one copy per device
     int dev = 0;
     (void)hipGetDevice(&dev);
     MEDP_ONCE_PER_DEVICE({
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_v7_kernel<TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         unsigned* sp = nullptr;
         if (hipGetSymbolAddress((void**)&sp, HIP_SYMBOL(g_v7_slots)) == hipSuccess) slots_of[dev % MEDP_MAX_DEVICES] = sp;
     });
     unsigned* slots = slots_of[dev % MEDP_MAX_DEVICES];
-    if (!slots) return -1;
-    // a ticket block nobody else is using: captured launches (replayed for the life of the graph) never share one
+    if (!slots) return nullptr;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     hipStreamIsCapturing(stream, &cs);
     unsigned s;
     if (cs == hipStreamCaptureStatusActive) {
         s = g_capture_next.fetch_add(1);
-        if (s >= (unsigned)CAPTURE_SLOTS) return -1;          // out of private slots: the caller falls back to v6
+        if (s >= (unsigned)CAPTURE_SLOTS) return nullptr;
         s += RING_SLOTS;
     } else {
         s = g_ring_next.fetch_add(1) % RING_SLOTS;
     }
+    return slots + (size_t)s * SLOT_WORDS;
+}
+
+template <int TAG>
+int launch_v7(const MedpGemmArgs& a, hipStream_t stream) {
+    MEDP_ONCE_PER_DEVICE({
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_v7_kernel<TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    });
+    unsigned* slot = ticket_block(stream);
+    if (!slot) return -1;                                  // out of private blocks: the caller falls back to v6
     // Resident workgroups: the FEWEST (a multiple of 8) that still finish in the same number of rounds as 256 would — qkv (585
     // tiles) and fc1 (780) need 3 and 4 rounds on 256 CUs and equally on 200; the 56 CUs left alone serve the other branches of
     // the step for the whole launch (teacher step 5.39 -> 5.19 ms, and the GEMMs themselves run 4 % faster: fewer L2 clients).
@@ -439,7 +448,7 @@ int launch_v7(const MedpGemmArgs& a, hipStream_t stream) {
     const int rounds = (ntiles + cap - 1) / cap;
     static const int fewest = [] { const char* e = getenv("MEDP_V7_FEWEST_WGS"); return e ? atoi(e) : 1; }();      // 0: always `cap` workgroups (A/B)
     const int nwg = fewest ? min(cap, ((ntiles + rounds - 1) / rounds + 7) & ~7) : cap;
-    gemm_bf16_nt_v7_kernel<TAG><<<nwg, 512, LDS_BYTES, stream>>>(a, slots + (size_t)s * SLOT_WORDS, g_trace);
+    gemm_bf16_nt_v7_kernel<TAG><<<nwg, 512, LDS_BYTES, stream>>>(a, slot, g_trace);
     MEDP_LAUNCH_CHECK("medp_gemm_bf16_nt(v7)");
     return 0;
 }
@@ -456,6 +465,8 @@ bool medp_gemm_v7_eligible(const MedpGemmArgs& a) {
 int medp_gemm_v7_launch(const MedpGemmArgs& a, int tag, void* stream) {
     return tag == 1 ? launch_v7<1>(a, (hipStream_t)stream) : launch_v7<0>(a, (hipStream_t)stream);
 }
+
+unsigned* medp_gemm_ticket_block(void* stream) { return ticket_block((hipStream_t)stream); }
 
 extern "C" int medp_gemm_persistent_cap(int cap) {
     const int v = cap <= 0 ? 0 : (cap < 8 ? 8 : (cap > NWG ? NWG : (cap & ~7)));

@@ -40,4 +40,6 @@ int medp_gemm_ragged_rows_launch(const MedpGemmArgs& a, int m_begin, void* strea
 // v7 = v6 made persistent for grids of more than 256 tiles (gemm_bf16_v7.hip); launch returns -1 when it has no private
 // ticket block left, and the caller launches v6 instead
 bool medp_gemm_v7_eligible(const MedpGemmArgs& a);
+// a private block of per-XCD ticket counters for ONE launch on `stream` (gemm_bf16_v7.hip; nullptr: none left)
+unsigned* medp_gemm_ticket_block(void* stream);
 int medp_gemm_v7_launch(const MedpGemmArgs& a, int tag, void* stream);
