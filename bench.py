@@ -31,6 +31,7 @@ import argparse
 import ctypes
 import json
 import os
+
 import socket
 import subprocess
 import sys
@@ -401,7 +402,7 @@ def main():
                 out = gstep.step(pool[i % n_pool], pool[(i + 1) % n_pool],          # (batch to train on, batch the next call will bring,
                                  pool[(i + 2) % n_pool] if (host and pipeline) else None)   # host batches: the one after, staged ahead)
             else:
-                out = gstep.step(pool[i % n_pool], pool[(i + 1) % n_pool])
+                out = gstep.step(pool[i % n_pool], pool[(i + 1) % n_pool], pool[(i + 2) % n_pool] if (host and pipeline) else None)
             sched.step()
             k = _state["n"]
             _pin[k % 2].copy_(out["loss"], non_blocking=True)

@@ -34,6 +34,7 @@ import os
 import torch
 
 from . import dp, engine
+from .streams import new_stream
 from .abi import check, lib, ptr, stream
 
 
@@ -58,9 +59,9 @@ class _GraphedStep:
         self._captured = False
         # the frozen forward may itself be cut into sub-batches on sibling streams (`_n_frozen_parts`): every one is forked from
         # the step's own stream — a fork nested inside a forked branch crashes hipStreamEndCapture on this runtime
-        self.frozen_streams = [torch.cuda.Stream(device=device) for _ in range(self._n_frozen_parts())] if self.pipeline else []
+        self.frozen_streams = [new_stream(device) for _ in range(self._n_frozen_parts())] if self.pipeline else []
         # warm-up on a side stream (allocator pools, lazy workspaces, optimiser state), as torch.cuda.graphs requires
-        s = torch.cuda.Stream(device=device)
+        s = new_stream(device)
         s.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(s):
             for it in range(max(int(warmup), 1)):
@@ -236,7 +237,9 @@ class GraphedTeacherStep(_GraphedStep):
         pixels of `next_batch`, into device staging buffers.  With pinned host tensors (a DataLoader with pin_memory=True) the
         38.5-MB pixel copy runs beside the current replay; the next call only pays device-to-device copies (~20 us)."""
         if not hasattr(self, "copy_stream"):
-            self.copy_stream = torch.cuda.Stream(device=self.device)
+            # normal priority (a stream of its own HIP priority class, high or low, made the step 7.6-8.9 ms instead of 5.05); its own
+            # hardware queue: streams.py
+            self.copy_stream = new_stream(self.device)
             self.stage = {k: torch.empty_like(getattr(self, a)) for k, a in
                           (("x_ts", "x_ts"), ("x_static", "x_static"), ("bin_ends", "bin_ends"), ("y_multi", "y_multi"),
                            ("y_multi_mask", "y_mask"), ("pixel_values", "pixels_next"))}
@@ -384,15 +387,59 @@ class GraphedStudentStep(_GraphedStep):
             self.z_cur.copy_(self._teacher_logit(self.nxt))
         self._expect = id(batch)
 
-    def step(self, batch: dict | None = None, next_batch: dict | None = None) -> dict:
-        if batch is not None:
-            if self.pipeline and self._expect != id(batch):
+    # ---- host batches: the next call's host->device copies beside this replay (as GraphedTeacherStep) --------------------------
+    def _stage_h2d(self, next_batch: dict, after_next: dict) -> None:
+        """What the NEXT call needs from the host: `next_batch`'s labels (its series are already on the device: this call's teacher
+        reads them) and ALL of `after_next` (the batch the teacher will run ahead on then) -> device staging buffers, on a copy stream."""
+        if not hasattr(self, "copy_stream"):
+            self.copy_stream = new_stream(self.device)
+            self.stage = {k: torch.empty_like(v) for k, v in self.nxt.items()}
+            self.stage["y"] = torch.empty_like(self.y)
+            self.h2d_done, self.stage_free = torch.cuda.Event(), torch.cuda.Event()
+            self.stage_free.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(self.stage_free)          # the previous call has taken its data out of the staging buffers
+            self._load(self.stage, after_next)
+            self.stage["y"].copy_(next_batch["y"], non_blocking=True)
+            self.h2d_done.record(self.copy_stream)
+        self._staged = (id(next_batch), id(after_next))
+
+    def _take_staged(self) -> None:
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(self.h2d_done)
+        for k in ("x_ts", "x_static", "bin_ends"):                 # the batch the teacher ran ahead on becomes the student's batch
+            self.cur[k].copy_(self.nxt[k])
+        self.y.copy_(self.stage["y"])
+        for k, v in self.nxt.items():
+            v.copy_(self.stage[k])
+        self.stage_free.record(cur)
+
+    def step(self, batch: dict | None = None, next_batch: dict | None = None, after_next: dict | None = None) -> dict:
+        """`after_next` (pipelined mode, HOST batches in pinned memory): the batch after `next_batch`; when given, the next call's
+        host->device copies are issued on a copy stream now, beside this replay, as in GraphedTeacherStep.  (Measured: unlike the
+        teacher step — 94 % of its resident-batch rate this way — the student step stays ~0.9 ms behind its resident-batch time with
+        or without the staging; how HIP maps streams onto hardware queues decides whether the copy really runs beside the graph,
+        DESIGN.md section 6.)"""
+        staged = self.pipeline and batch is not None and next_batch is not None and \
+            getattr(self, "_staged", None) == (id(batch), id(next_batch))
+        if staged:
+            if self._expect != id(batch):
                 self.prime(batch)
-            self._load(self.cur, batch, with_pixels=not self.pipeline)
-            self.y.copy_(batch["y"], non_blocking=True)
-        if self.pipeline:
-            nb = next_batch if next_batch is not None else batch
-            if nb is not None:
-                self._load(self.nxt, nb)
-                self._expect = id(nb)
+            self._take_staged()
+            self._expect = id(next_batch)
+        else:
+            if batch is not None:
+                if self.pipeline and self._expect != id(batch):
+                    self.prime(batch)
+                self._load(self.cur, batch, with_pixels=not self.pipeline)
+                self.y.copy_(batch["y"], non_blocking=True)
+            if self.pipeline:
+                nb = next_batch if next_batch is not None else batch
+                if nb is not None:
+                    self._load(self.nxt, nb)
+                    self._expect = id(nb)
+        if self.pipeline and after_next is not None and next_batch is not None and not next_batch["pixel_values"].is_cuda:
+            self._stage_h2d(next_batch, after_next)
+        else:
+            self._staged = None
         return self._replay()

@@ -44,7 +44,8 @@ def _side_stream(device):
         return None
     key = device.index if device.index is not None else torch.cuda.current_device()
     if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+        from .streams import new_stream
+        _SIDE_STREAMS[key] = new_stream(device)
     return _SIDE_STREAMS[key]
 
 

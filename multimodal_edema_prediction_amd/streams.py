@@ -1,0 +1,42 @@
+"""Where this package's extra HIP streams come from.
+
+HIP multiplexes all streams of one priority over a few hardware queues (GPU_MAX_HW_QUEUES, default 4; a new stream goes to the
+queue with the fewest streams on it) and a hardware queue executes its packets in order, so WHICH streams share a queue decides
+what really runs concurrently — and it is an accident of creation order.  Measured on one box with otherwise identical code
+(DESIGN.md section 6): teacher step 5.0-13 ms and student step 7.8-14 ms across GPU_MAX_HW_QUEUES = 2 ... 16; with more than 4
+queues some arrangements fall off a cliff (13 ms), with 4 the spread is +-8 %.  Streams created through the HIP runtime
+(`MEDP_RAW_STREAMS=1`, so that torch's pool of 32 streams per priority never exists and every live stream could have a queue of
+its own with GPU_MAX_HW_QUEUES=16) were uniformly WORSE (13 ms): many concurrently active hardware queues is the slow case.
+Default therefore: torch's pool streams and the runtime's default of 4 queues."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HIP = None
+_KEEP = []          # (handle, ExternalStream): raw streams live as long as the process
+
+
+def new_stream(device=None) -> "torch.cuda.Stream":
+    """A stream on `device`: of torch's pool (default) or, with MEDP_RAW_STREAMS=1, a non-blocking HIP stream made here."""
+    global _HIP
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if os.environ.get("MEDP_RAW_STREAMS", "0") != "1":
+        return torch.cuda.Stream(device=dev)
+    try:
+        if _HIP is None:
+            _HIP = ctypes.CDLL("libamdhip64.so")
+            _HIP.hipStreamCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+            _HIP.hipStreamCreateWithFlags.restype = ctypes.c_int
+        h = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            rc = _HIP.hipStreamCreateWithFlags(ctypes.byref(h), 1)          # 1 = hipStreamNonBlocking
+        if rc != 0 or not h.value:
+            raise OSError(f"hipStreamCreateWithFlags -> {rc}")
+        s = torch.cuda.ExternalStream(h.value, device=dev)
+        _KEEP.append((h, s))
+        return s
+    except (OSError, AttributeError):
+        return torch.cuda.Stream(device=dev)

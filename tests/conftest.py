@@ -1,6 +1,7 @@
 import os
 import sys
 
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -92,3 +92,38 @@ def test_teacher_one_batch_ahead_is_bit_identical(split):
         assert torch.equal(p0[k], p1[k]), k
     for k in b0:
         assert torch.equal(b0[k], b1[k]), k
+
+
+def test_staged_host_batches_are_bit_identical_to_resident_batches():
+    """Host batches in pinned memory, the next call's copies issued one call ahead on a copy stream (`after_next`): same losses,
+    parameters and buffers as device-resident batches — including a call whose announced batches turn out wrong (the staged data
+    is then ignored and the direct path taken)."""
+    from multimodal_edema_prediction_amd.graph_step import GraphedStudentStep
+    from multimodal_edema_prediction_amd.losses_duett import StudentKDLoss
+    from multimodal_edema_prediction_amd.optim import FusedAdamW
+    dev = torch.device("cuda")
+    raw = _batches(4)
+    pin = lambda v: (torch.stack(tuple(v)) if not torch.is_tensor(v) else v).float().pin_memory()
+    host = [{k: pin(v) for k, v in b.items()} for b in raw]
+    order = [0, 1, 2, 3, 0, 2, 1, 3]                  # position 5 breaks the announced order
+    announce = [1, 2, 3, 0, 1, 1, 3, 0]
+    after = [2, 3, 0, 1, 2, 3, 0, 1]
+    kd = StudentKDLoss("vanilla_kl", 4.0, 0.5)
+
+    def run(staged):
+        s, t = _build(dev)
+        opt = FusedAdamW([p for p in s.parameters() if p.requires_grad], lr=1e-3, weight_decay=5e-2)
+        gs = GraphedStudentStep(s, t, kd, opt, raw[0], dev, warmup=2)
+        pool = host if staged else [{k: v.to(dev) for k, v in b.items()} for b in host]
+        losses = []
+        for k, n, a in zip(order, announce, after):
+            losses.append(float(gs.step(pool[k], pool[n], pool[a] if staged else None)["loss"].item()))
+        return losses, {k: p.detach().clone() for k, p in s.named_parameters()}, {k: b.detach().clone() for k, b in s.named_buffers()}
+
+    l0, p0, b0 = run(False)
+    l1, p1, b1 = run(True)
+    np.testing.assert_array_equal(np.array(l1), np.array(l0))
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
+    for k in b0:
+        assert torch.equal(b0[k], b1[k]), k
