@@ -417,9 +417,9 @@ class GraphedStudentStep(_GraphedStep):
     def step(self, batch: dict | None = None, next_batch: dict | None = None, after_next: dict | None = None) -> dict:
         """`after_next` (pipelined mode, HOST batches in pinned memory): the batch after `next_batch`; when given, the next call's
         host->device copies are issued on a copy stream now, beside this replay, as in GraphedTeacherStep.  (Measured: unlike the
-        teacher step — 94 % of its resident-batch rate this way — the student step stays ~0.9 ms behind its resident-batch time with
-        or without the staging; how HIP maps streams onto hardware queues decides whether the copy really runs beside the graph,
-        DESIGN.md section 6.)"""
+        teacher step — 98 % of its resident-batch rate this way — the student step stays ~0.85 ms behind its resident-batch time with
+        or without the staging: the 38.5-MB pixel copy costs its full duration wherever it is issued (before or after the launch,
+        any pool stream, a raw HIP stream), except with GPU_MAX_HW_QUEUES = 3 or 8 where it overlaps (7.8 ms) — DESIGN.md section 6.)"""
         staged = self.pipeline and batch is not None and next_batch is not None and \
             getattr(self, "_staged", None) == (id(batch), id(next_batch))
         if staged:

@@ -19,11 +19,13 @@ _HIP = None
 _KEEP = []          # (handle, ExternalStream): raw streams live as long as the process
 
 
-def new_stream(device=None) -> "torch.cuda.Stream":
-    """A stream on `device`: of torch's pool (default) or, with MEDP_RAW_STREAMS=1, a non-blocking HIP stream made here."""
+def new_stream(device=None, raw=None) -> "torch.cuda.Stream":
+    """A stream on `device`: of torch's pool (default) or, with raw=True / MEDP_RAW_STREAMS=1, a non-blocking HIP stream made here."""
     global _HIP
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    if os.environ.get("MEDP_RAW_STREAMS", "0") != "1":
+    if raw is None:
+        raw = os.environ.get("MEDP_RAW_STREAMS", "0") == "1"
+    if not raw:
         return torch.cuda.Stream(device=dev)
     try:
         if _HIP is None:
