@@ -18,6 +18,7 @@
 // A workgroup that draws a ticket past the end leaves; the last one to leave zeroes the tickets for the next launch.
 // The ticket block is private to one launch (host side: a ring for eager launches, never-reused slots under stream capture).
 #include <stdlib.h>
+#include <string.h>
 
 #include <atomic>
 
@@ -78,7 +79,7 @@ constexpr int NWG = 256;                                               // reside
 #endif
 
 template <int TAG>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v7_kernel(const MedpGemmArgs p, unsigned* slot, unsigned long long* trace) {
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v7_kernel(const MedpGemmArgs p, unsigned* slot, unsigned long long* trace, const int MB, const int SN) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -99,7 +100,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v7_kernel(const MedpGemmA
     auto origin = [&](int bid, int& m0, int& n0) {
         if (bid < nfull) {
             const int wg = bid < full8 ? (bid & 7) * (full8 >> 3) + (bid >> 3) : bid;
-            constexpr int MB = 8, SN = 4;
             const int band = wg / (MB * tiles_n), rb = wg % (MB * tiles_n);
             const int mb = min(MB, tm_full - band * MB);
             const int sc = rb / (mb * SN), r2 = rb % (mb * SN);
@@ -448,7 +448,17 @@ int launch_v7(const MedpGemmArgs& a, hipStream_t stream) {
     const int rounds = (ntiles + cap - 1) / cap;
     static const int fewest = [] { const char* e = getenv("MEDP_V7_FEWEST_WGS"); return e ? atoi(e) : 1; }();      // 0: always `cap` workgroups (A/B)
     const int nwg = fewest ? min(cap, ((ntiles + rounds - 1) / rounds + 7) & ~7) : cap;
-    gemm_bf16_nt_v7_kernel<TAG><<<nwg, 512, LDS_BYTES, stream>>>(a, slot, g_trace);
+    // Tile walk inside an XCD: blocks of MB row-tiles x SN column-tiles (8 x 4 = one round of an XCD's 32 CUs; MEDP_V7_BLOCK=MBxSN
+    // overrides).  Measured (FETCH_SIZE per launch, mean of qkv / fc1; in-box step time): 256 workgroups 8x4: 51.1 k KiB, 5.26 ms;
+    // 200 workgroups 8x4: 69.2 k, 5.03-5.11 ms (the rounds of 25 per XCD straddle the blocks, the K-loops drift out of step and
+    // re-fetch panels); 200 with 5x5: 71.1 k, same time; 192 workgroups 8x3 + the ragged rows as their own launch (every round
+    // exactly one block): 48.0 k but 5.25 ms.  HBM traffic is not what binds these GEMMs (142.5 MB algorithmic = 18 us at 8 TB/s
+    // against 65-100 us): the fastest arrangement is kept, the extra re-fetch is reported (profiles/traffic.json).
+    static const int env_mb = [] { const char* e = getenv("MEDP_V7_BLOCK"); return e ? atoi(e) : 0; }();
+    static const int env_sn = [] { const char* e = getenv("MEDP_V7_BLOCK"); const char* x = e ? strchr(e, 'x') : nullptr; return x ? atoi(x + 1) : 0; }();
+    int mb = 8, sn = 4;
+    if (env_mb > 0 && env_sn > 0) { mb = env_mb; sn = env_sn; }
+    gemm_bf16_nt_v7_kernel<TAG><<<nwg, 512, LDS_BYTES, stream>>>(a, slot, g_trace, mb, sn);
     MEDP_LAUNCH_CHECK("medp_gemm_bf16_nt(v7)");
     return 0;
 }

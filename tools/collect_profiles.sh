@@ -64,4 +64,17 @@ rocprofv3 --pmc $SQA --output-format csv -d $O/${TAG}_pmc_attn -- python3 $R/too
 } > $O/${TAG}_pmc_attention.txt
 rm -rf $O/${TAG}_pmc_attn
 cat $O/${TAG}_pmc_embed.txt $O/${TAG}_pmc_attention.txt
+echo "[collect] branch timing (tools/time_branches.py)"
+{
+  echo "# python3 tools/time_branches.py [student]   ($TAG; HBM-resident batch; whole captured step vs each branch replayed alone; in-kernel launch clocks of the 48 block GEMMs)"
+  python3 $R/tools/time_branches.py 2>/dev/null | grep -E "GEMMs|whole step"
+  python3 $R/tools/time_branches.py student 2>/dev/null | grep -E "GEMMs|whole step"
+} > $O/${TAG}_branch_times.txt
+cat $O/${TAG}_branch_times.txt
+{
+  echo "# MEDP_ATTN_FEWQ=0 / default: python3 tools/time_attn_small.py   ($TAG; perceiver attention cores, isolated launches incl. ~10 us of Python per call)"
+  MEDP_ATTN_FEWQ=0 python3 $R/tools/time_attn_small.py 2>/dev/null | grep FEWQ
+  python3 $R/tools/time_attn_small.py 2>/dev/null | grep FEWQ
+} > $O/${TAG}_attn_few_query.txt
+cat $O/${TAG}_attn_few_query.txt
 echo "[collect] done"
