@@ -87,6 +87,15 @@ class _GraphedStep:
             before_capture()
         self.g_opt = None
         self.g_fb = torch.cuda.CUDAGraph()
+        # Hardware-queue phase.  HIP multiplexes streams over 4 in-order hardware queues, a new stream going to the queue with the
+        # fewest streams on it; the graph's internal branch streams are made when it is instantiated, so every raw HIP stream created
+        # right before the capture moves them on by one queue.  One of the four phases is bad — the 38.5-MB pixel copy staged for the
+        # next call then costs its full 0.85 ms instead of running beside the replay: teacher 6.05-6.07 ms in phase 2 (5.16-5.25 in the
+        # others), student 8.58-8.67 ms in phase 0 (7.84-7.93 in the others); the pattern repeats with period 4 and does not depend on
+        # which stream issues the copy (pool stream, raw stream, its own replay stream: all measured, profiles/r02_ab_experiments.txt
+        # section 7) — what the copy collides with was not identified.  Three pad streams put both steps in a good phase in the
+        # one-process-per-GPU setting measured; MEDP_PRE_CAPTURE_STREAMS overrides.
+        self._pad_streams = [new_stream(device, raw=True) for _ in range(int(os.environ.get("MEDP_PRE_CAPTURE_STREAMS", "3")))]
         if not self.split:
             with torch.cuda.graph(self.g_fb):
                 self._advance()
@@ -104,6 +113,7 @@ class _GraphedStep:
                 with torch.cuda.graph(self.g_opt):
                     self.opt.step()
         torch.cuda.synchronize(device)
+        self.copy_stream = new_stream(device)
         self._captured = True
         self.opt._step = int(self.opt.dev_step.item())      # capture ran opt.step() on the host without executing it
 
@@ -236,10 +246,9 @@ class GraphedTeacherStep(_GraphedStep):
         """Enqueue, on the copy stream, the host->device copies the NEXT call will need: the small tensors of `batch` and the
         pixels of `next_batch`, into device staging buffers.  With pinned host tensors (a DataLoader with pin_memory=True) the
         38.5-MB pixel copy runs beside the current replay; the next call only pays device-to-device copies (~20 us)."""
-        if not hasattr(self, "copy_stream"):
-            # normal priority (a stream of its own HIP priority class, high or low, made the step 7.6-8.9 ms instead of 5.05); its own
-            # hardware queue: streams.py
-            self.copy_stream = new_stream(self.device)
+        if not hasattr(self, "stage"):
+            # (the copy stream — normal priority: a stream of its own HIP priority class, high or low, made the step 7.6-8.9 ms
+            # instead of 5.05 — is made in _setup, next to the replay stream)
             self.stage = {k: torch.empty_like(getattr(self, a)) for k, a in
                           (("x_ts", "x_ts"), ("x_static", "x_static"), ("bin_ends", "bin_ends"), ("y_multi", "y_multi"),
                            ("y_multi_mask", "y_mask"), ("pixel_values", "pixels_next"))}
@@ -391,8 +400,7 @@ class GraphedStudentStep(_GraphedStep):
     def _stage_h2d(self, next_batch: dict, after_next: dict) -> None:
         """What the NEXT call needs from the host: `next_batch`'s labels (its series are already on the device: this call's teacher
         reads them) and ALL of `after_next` (the batch the teacher will run ahead on then) -> device staging buffers, on a copy stream."""
-        if not hasattr(self, "copy_stream"):
-            self.copy_stream = new_stream(self.device)
+        if not hasattr(self, "stage"):
             self.stage = {k: torch.empty_like(v) for k, v in self.nxt.items()}
             self.stage["y"] = torch.empty_like(self.y)
             self.h2d_done, self.stage_free = torch.cuda.Event(), torch.cuda.Event()
