@@ -341,6 +341,7 @@ def main():
     graph_error = None
     if want_graph:
         from multimodal_edema_prediction_amd.graph_step import GraphedStudentStep, GraphedTeacherStep
+        os.environ.setdefault("MEDP_PHASE_CHECK", "1")          # report which hardware-queue phase the captured step sits in (graph_step._setup)
         arm = lambda: abi.check(L.medp_gemm_profile_enable(2), "gemm_profile_enable")     # launch clocks ride in the captured GEMMs
         try:
             if cfg == "teacher":
@@ -512,6 +513,8 @@ def main():
         "config": {"workload": workload, "config": cfg, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "batch_location": "hbm (resident)" if args.resident else "pinned host memory: H2D + feats_to_input inside the timed step",
                    "resident_batch_samples_per_s": round(world * B * args.steps / dt_res, 2) if dt_res else None,
+                   # graph_step's hardware-queue phase check: (pad streams, ms a step loses to the staged pixel copy, ms of that copy alone)
+                   "hw_queue_phase": getattr(gstep, "phase_log", None),
                    "gflop_per_sample": gps,
                    "step_mfma_fraction_of_peak": None if gps is None else round(value * gps / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
                    "last_loss": round(last_loss, 5), "execution": execution,

@@ -85,17 +85,31 @@ class _GraphedStep:
         self._zero_grads()
         if before_capture is not None:
             before_capture()
+        # Hardware-queue phase.  HIP multiplexes streams over 4 in-order hardware queues, a new stream going to the queue with the
+        # fewest streams on it; every raw HIP stream created before the process's FIRST graph capture moves the graph's internal branch
+        # streams on by one queue.  One of the four phases is bad — the 38.5-MB pixel copy staged for the next call then costs its full
+        # 0.85 ms instead of running beside the replay: teacher 6.05-6.07 ms in phase 2 (5.16-5.25 in the others), student 8.58-8.67 ms
+        # in phase 0 (7.84-7.93 in the others); period 4; independent of which stream issues the copy (pool stream, raw stream, the
+        # replay on a stream of its own) — what the copy collides with was not identified.  Nor can the phase be changed once the first
+        # graph exists: capturing again after more pad streams, or with dummy branches forked ahead of the frozen one, stays in the phase
+        # (profiles/r02_ab_experiments.txt sections 7, 9, 10).  Three pad streams is the good phase of every one-process-per-GPU run
+        # measured (MEDP_PRE_CAPTURE_STREAMS overrides).  MEDP_PHASE_CHECK=1 (bench.py sets it) MEASURES the phase the step ended up in:
+        # a few steps with staged host batches against resident ones on a snapshot of everything a step writes, restored afterwards;
+        # `phase_log` = (pad streams, ms lost per step to the staged copy, ms of the copy alone).
+        self._pad_streams = [new_stream(device, raw=True) for _ in range(int(os.environ.get("MEDP_PRE_CAPTURE_STREAMS", "3")))]
+        self.copy_stream = new_stream(device)
+        self._capture()
+        self.phase_log = None
+        if self.pipeline and os.environ.get("MEDP_PHASE_CHECK", "0") == "1":
+            penalty, t_copy = self._staging_penalty()
+            self.phase_log = (len(self._pad_streams), round(penalty * 1e3, 3), round(t_copy * 1e3, 3))
+        self._captured = True
+        self.opt._step = int(self.opt.dev_step.item())      # capture ran opt.step() on the host without executing it
+
+    def _capture(self):
+        device = self.device
         self.g_opt = None
         self.g_fb = torch.cuda.CUDAGraph()
-        # Hardware-queue phase.  HIP multiplexes streams over 4 in-order hardware queues, a new stream going to the queue with the
-        # fewest streams on it; the graph's internal branch streams are made when it is instantiated, so every raw HIP stream created
-        # right before the capture moves them on by one queue.  One of the four phases is bad — the 38.5-MB pixel copy staged for the
-        # next call then costs its full 0.85 ms instead of running beside the replay: teacher 6.05-6.07 ms in phase 2 (5.16-5.25 in the
-        # others), student 8.58-8.67 ms in phase 0 (7.84-7.93 in the others); the pattern repeats with period 4 and does not depend on
-        # which stream issues the copy (pool stream, raw stream, its own replay stream: all measured, profiles/r02_ab_experiments.txt
-        # section 7) — what the copy collides with was not identified.  Three pad streams put both steps in a good phase in the
-        # one-process-per-GPU setting measured; MEDP_PRE_CAPTURE_STREAMS overrides.
-        self._pad_streams = [new_stream(device, raw=True) for _ in range(int(os.environ.get("MEDP_PRE_CAPTURE_STREAMS", "3")))]
         if not self.split:
             with torch.cuda.graph(self.g_fb):
                 self._advance()
@@ -113,9 +127,64 @@ class _GraphedStep:
                 with torch.cuda.graph(self.g_opt):
                     self.opt.step()
         torch.cuda.synchronize(device)
-        self.copy_stream = new_stream(device)
-        self._captured = True
         self.opt._step = int(self.opt.dev_step.item())      # capture ran opt.step() on the host without executing it
+
+    def _written_state(self):
+        """Every tensor a replay writes and a later replay (or the caller) reads: parameters, optimiser state and step counter, the
+        dropout epoch, module buffers (BatchNorm statistics), the subclass's hand-over buffers."""
+        ts = list(self.params)
+        for p in self.params:
+            ts += [v for v in self.opt.state.get(p, {}).values() if torch.is_tensor(v)]
+        ts += [self.opt.dev_step, self.epoch] + list(self._handover_tensors())
+        return ts
+
+    def _staging_penalty(self, n: int = 4):
+        """(seconds a step takes longer with HOST batches — pinned, staged one call ahead exactly as `step()` does it — than with
+        device-resident ones, seconds the pixel copy takes alone).  The steps train: everything they write is snapshotted first and
+        restored afterwards (buffers by name: the training path may re-bind them); with more than one rank every rank takes the
+        largest penalty measured, so all decide alike."""
+        import time
+        dev_b, host_b = self._calib_batches()
+        state = self._written_state()
+        saved = [t.detach().clone() for t in state]
+        bufs = [(m, k, b.detach().clone()) for m in self._stateful_modules() for k, b in m.named_buffers()]
+        host_step, expect = self.opt._step, self._expect
+
+        def timed(pool, staged):
+            for i in range(2):
+                self.step(pool[i % 2], pool[(i + 1) % 2], pool[i % 2] if staged else None)
+            torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
+            for i in range(n):
+                self.step(pool[i % 2], pool[(i + 1) % 2], pool[i % 2] if staged else None)
+            torch.cuda.synchronize(self.device)
+            return (time.perf_counter() - t0) / n
+
+        t_res, t_host = timed(dev_b, False), timed(host_b, True)
+        px = host_b[0]["pixel_values"]
+        dst = torch.empty_like(dev_b[0]["pixel_values"])
+        torch.cuda.synchronize(self.device)
+        t0 = time.perf_counter()
+        with torch.cuda.stream(self.copy_stream):
+            for _ in range(n):
+                dst.copy_(px, non_blocking=True)
+        torch.cuda.synchronize(self.device)
+        t_copy = (time.perf_counter() - t0) / n
+        with torch.no_grad():
+            for t, v in zip(state, saved):
+                t.copy_(v)
+            for m, k, v in bufs:
+                b = m.get_buffer(k)
+                if not torch.equal(b, v):          # only what a step really moved (BatchNorm statistics of the trained part): writing a FROZEN
+                    b.copy_(v)                     # module's buffer bumps its version, its prepared weights are rebuilt — and the graph reads the old ones
+        self.opt._step, self._expect, self._staged = host_step, expect, None
+        torch.cuda.synchronize(self.device)
+        penalty = t_host - t_res
+        if self.world > 1:
+            pt = torch.tensor([penalty, t_copy], device=self.device, dtype=torch.float64)
+            torch.distributed.all_reduce(pt, op=torch.distributed.ReduceOp.MAX, group=self.group)
+            penalty, t_copy = float(pt[0]), float(pt[1])
+        return penalty, t_copy
 
     # ---- pieces -------------------------------------------------------------------------------------------------------------
     def _zero_grads(self):
@@ -210,6 +279,17 @@ class GraphedTeacherStep(_GraphedStep):
 
     def _stateful_modules(self):
         return [self.teacher]
+
+    def _handover_tensors(self):
+        return [self.tok_cur] if self.pipeline else []
+
+    def _calib_batches(self):
+        """Two device-resident and two pinned-host copies of the batch in the static buffers (distinct dict objects: `step` tells
+        batches apart by identity)."""
+        d = {"x_ts": self.x_ts.clone(), "x_static": self.x_static.clone(), "bin_ends": self.bin_ends.clone(),
+             "y_multi": self.y_multi.clone(), "y_multi_mask": self.y_mask.clone(), "pixel_values": self.pixels.clone()}
+        h = {k: v.cpu().pin_memory() for k, v in d.items()}
+        return [dict(d), dict(d)], [dict(h), dict(h)]
 
     def _hand_over(self):
         self.tok_cur.copy_(self.tok_next)      # after the backward: the weight-gradient GEMM of img_proj reads tok_cur
@@ -364,6 +444,15 @@ class GraphedStudentStep(_GraphedStep):
 
     def _stateful_modules(self):
         return [self.student, self.teacher]
+
+    def _handover_tensors(self):
+        return [self.z_cur]
+
+    def _calib_batches(self):
+        d = {k: v.clone() for k, v in self.cur.items()}
+        d["y"] = self.y.clone()
+        h = {k: v.cpu().pin_memory() for k, v in d.items()}
+        return [dict(d), dict(d)], [dict(h), dict(h)]
 
     def _hand_over(self):
         if not self._captured:

@@ -160,3 +160,45 @@ def test_split_step_leaves_unused_parameters_alone():
     np.testing.assert_allclose(l1, l0, rtol=1e-6)
     for (k, a), (_, b) in zip(te0.named_parameters(), te1.named_parameters()):
         assert float((a - b).abs().max()) <= 1e-6, k
+
+
+@pytest.mark.parametrize("kind", ["teacher", "student"])
+def test_phase_check_leaves_the_training_state_untouched(kind, monkeypatch):
+    """MEDP_PHASE_CHECK=1 (bench.py): after the capture the step runs a few times with staged host batches and with resident ones to
+    see which hardware-queue phase it sits in — on a snapshot of everything a step writes.  The steps that follow must be the ones
+    that follow without the check, bit for bit (losses, parameters, buffers, optimiser step count)."""
+    import test_gpu_model as T
+    from multimodal_edema_prediction_amd.graph_step import GraphedStudentStep, GraphedTeacherStep
+    from multimodal_edema_prediction_amd.losses_duett import DualPathologyLoss, StudentKDLoss
+    from multimodal_edema_prediction_amd.optim import FusedAdamW, make_param_groups
+    dev = torch.device("cuda")
+    start = T.META["teacher_batch_start"]
+    batches = [T.make_batch(T.CCFG, start + 97 * i, T.B, mode="teacher") for i in range(3)]
+
+    def run(check):
+        monkeypatch.setenv("MEDP_PHASE_CHECK", "1" if check else "0")
+        if kind == "teacher":
+            model = T.build_teacher()
+            opt = FusedAdamW(make_param_groups(model, 8e-5), weight_decay=5e-2)
+            gs = GraphedTeacherStep(model, DualPathologyLoss(torch.ones(T.K), None, 0.5, 0.5, 1.0).to(dev), opt, batches[0], dev, warmup=2,
+                                    pipeline_cxr=True)
+        else:
+            import test_gpu_student_graph as S
+            sb = S._batches(3)
+            model, teacher = S._build(dev, dropout=0.1)
+            opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3, weight_decay=5e-2)
+            gs = GraphedStudentStep(model, teacher, StudentKDLoss("vanilla_kl", 4.0, 0.5), opt, sb[0], dev, warmup=2)
+        assert (gs.phase_log is not None) == check
+        pool = batches if kind == "teacher" else sb
+        losses = [float(gs.step(pool[i % 3], pool[(i + 1) % 3])["loss"].item()) for i in range(4)]
+        return (losses, {k: p.detach().clone() for k, p in model.named_parameters()}, {k: b.detach().clone() for k, b in model.named_buffers()},
+                opt._step)
+
+    l0, p0, b0, s0 = run(False)
+    l1, p1, b1, s1 = run(True)
+    np.testing.assert_array_equal(np.array(l1), np.array(l0))
+    assert s0 == s1
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
+    for k in b0:
+        assert torch.equal(b0[k], b1[k]), k
