@@ -105,6 +105,19 @@ class _GraphedStep:
             self.phase_log = (len(self._pad_streams), round(penalty * 1e3, 3), round(t_copy * 1e3, 3))
         self._captured = True
         self.opt._step = int(self.opt.dev_step.item())      # capture ran opt.step() on the host without executing it
+        # The graph holds raw pointers into the PREPARED weights of the frozen modules (DuETT / CXR `_prep`: stacked, folded, bf16)
+        # and into the cached bf16 copies of frozen Linear weights.  Those are rebuilt — and the old tensors freed — when somebody
+        # writes a frozen parameter or buffer and then calls the module eagerly: keep what the capture saw alive, and refuse to
+        # replay over changed weights (`_replay`) instead of training on stale ones.
+        from . import autograd_ops as _A
+        self._prep_refs = [(m, m._prep) for root in self._stateful_modules() for m in root.modules() if getattr(m, "_prep", None) is not None]
+        self._cache_refs = [v for slot in _A._W_CACHE.values() for v in slot.values()]
+
+    def _check_frozen_unchanged(self):
+        for m, prep in self._prep_refs:
+            if m._prep is not prep:
+                raise RuntimeError(f"{type(m).__name__}: frozen weights were modified after the step was captured; build a new "
+                                   f"{type(self).__name__} (the captured graph still reads the old prepared weights)")
 
     def _capture(self):
         device = self.device
@@ -227,6 +240,8 @@ class _GraphedStep:
 
     def _replay(self):
         """refresh_lrs + the graph(s) of one step on the current stream."""
+        if self._captured:
+            self._check_frozen_unchanged()
         self.opt.refresh_lrs()                       # this step's learning rates -> device table, ahead of the replay
         self.g_fb.replay()
         if not self.split:

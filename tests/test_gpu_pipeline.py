@@ -202,3 +202,24 @@ def test_phase_check_leaves_the_training_state_untouched(kind, monkeypatch):
         assert torch.equal(p0[k], p1[k]), k
     for k in b0:
         assert torch.equal(b0[k], b1[k]), k
+
+
+def test_replay_refuses_frozen_weights_changed_after_capture():
+    """The captured graph reads the frozen encoders' PREPARED weights by address: writing a frozen parameter and calling the module
+    eagerly rebuilds them.  The step keeps the captured ones alive and raises instead of training on stale weights."""
+    import test_gpu_model as T
+    from multimodal_edema_prediction_amd.graph_step import GraphedTeacherStep
+    from multimodal_edema_prediction_amd.losses_duett import DualPathologyLoss
+    from multimodal_edema_prediction_amd.optim import FusedAdamW, make_param_groups
+    dev = torch.device("cuda")
+    batch = T.make_batch(T.CCFG, T.META["teacher_batch_start"], T.B, mode="teacher")
+    te = T.build_teacher()
+    opt = FusedAdamW(make_param_groups(te, 8e-5), weight_decay=5e-2)
+    gs = GraphedTeacherStep(te, DualPathologyLoss(torch.ones(T.K), None, 0.5, 0.5, 1.0).to(dev), opt, batch, dev, warmup=2, pipeline_cxr=True)
+    l0 = float(gs.step(batch, batch)["loss"].item())
+    assert np.isfinite(l0)
+    with torch.no_grad():
+        te.cxr.backbone.layernorm.weight.mul_(1.5)          # a frozen parameter changes ...
+        te.cxr.forward_bf16(batch["pixel_values"].to(dev))  # ... and an eager call rebuilds the prepared weights
+    with pytest.raises(RuntimeError, match="frozen weights were modified"):
+        gs.step(batch, batch)
