@@ -89,6 +89,16 @@ int medp_attn_fwd_dh64(const void* q, const void* k, const void* v, void* o, int
  * qkv: fp32 rows [B*N, ld] holding q | k | v column blocks of H*dh each (the fused QKV GEMM's output); o: bf16 [B*N, ldo].
  * Returns -2 (nothing launched) for shapes it is not built for: the caller then uses medp_attn_small_fwd. */
 int medp_attn_dh16_fwd(const float* qkv, int ld, void* o_bf16, int ldo, int B, int N, int H, int dh, float scale, void* stream);
+/* The same attention in TRAINING form (the student-KD step: dropout on the probabilities, gradients to q, k, v; autograd of
+ * duett/duett.py:95-105): forward writes fp32 o [B*N][ldo] and the rows' log2-sum-exp lse [B*H*N]; backward writes dQ | dK | dV into
+ * the column blocks of dqkv [B*N][lddqkv] (delta_ws: B*H*N floats of scratch).  Three MFMA kernels, a wave per 16-row tile, no LDS,
+ * nothing added into memory (bitwise reproducible); same dropout stream as medp_attn_small_*.  Both return -2 (nothing launched)
+ * for unsupported shapes. */
+int medp_attn_dh16_train_fwd(const float* qkv, int ld, float* o, int ldo, float* lse, int B, int N, int H, int dh, float scale,
+                             float dropout_p, unsigned seed, unsigned stream_id, void* stream);
+int medp_attn_dh16_train_bwd(const float* dout, int lddo, const float* qkv, int ld, const float* lse, float* delta_ws, float* dqkv,
+                             int lddqkv, int B, int N, int H, int dh, float scale, float dropout_p, unsigned seed, unsigned stream_id,
+                             void* stream);
 /* Training form (--unfreeze_cxr, run.py:184-187): the same forward that also writes lse[B,H,S], the log2-domain logsumexp of the
  * scaled scores, and the flash backward that consumes it.  prep: dsum[b,h,s] = <dout, o> and the bf16 copy of dout.
  * bwd: dq/dk/dv fp32 with row stride ldd (e.g. the three column blocks of one [B*S, 3*H*64] buffer); q/k/v/dout_bf16 bf16. */

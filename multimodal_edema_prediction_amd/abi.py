@@ -66,6 +66,8 @@ SIGNATURES = {
     "medp_gemm_profile_collect": (I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_longlong), ctypes.POINTER(ctypes.c_double)]),
     "medp_attn_fwd_dh64": (I, [P, P, P, P, I, I, I, I, I, I, I, F, P]),
     "medp_attn_dh16_fwd": (I, [P, I, P, I, I, I, I, I, F, P]),
+    "medp_attn_dh16_train_fwd": (I, [P, I, P, I, P, I, I, I, I, F, F, U, U, P]),
+    "medp_attn_dh16_train_bwd": (I, [P, I, P, I, P, P, P, I, I, I, I, I, F, F, U, U, P]),
     "medp_attn_fwd_dh64_lse": (I, [P, P, P, P, P, I, I, I, I, I, I, I, F, P]),
     "medp_attn_bwd_dh64_prep": (I, [P, I, P, I, P, I, P, I, I, I, P]),
     "medp_attn_bwd_dh64": (I, [P, P, P, I, P, I, P, P, P, P, P, I, I, I, I, F, P]),

@@ -200,8 +200,13 @@ class ScaleNormFn(torch.autograd.Function):
         return dx, dg, None
 
 
+_MFMA_ATTN = __import__("os").environ.get("MEDP_DUETT_TRAIN_MFMA_ATTN", "1") == "1"
+
+
 class SelfAttnQKVFn(torch.autograd.Function):
-    """qkv [B, N, 3*H*dh] (q | k | v column blocks) -> [B, N, H*dh]; dense softmax, dropout on the probabilities."""
+    """qkv [B, N, 3*H*dh] (q | k | v column blocks) -> [B, N, H*dh]; dense softmax, dropout on the probabilities.
+    bf16 mode: the MFMA kernels of csrc/attention_dh16_train.hip (head dim <= 16, N <= 272); fp32 kernel mode or other shapes: the
+    fp32 VALU kernels of csrc/attention_small.hip.  Both draw the same dropout mask."""
 
     @staticmethod
     def forward(ctx, qkv, H, p, seed, sid):
@@ -209,21 +214,35 @@ class SelfAttnQKVFn(torch.autograd.Function):
         B, N, D3 = qkv.shape
         D = D3 // 3
         dh = D // H
+        ctx.cfg = (H, p, seed, sid)
+        if _MFMA_ATTN and Fn.precision() != "fp32":
+            o = torch.empty((B, N, D), dtype=torch.float32, device=qkv.device)
+            lse = torch.empty((B * H * N,), dtype=torch.float32, device=qkv.device)
+            rc = lib().medp_attn_dh16_train_fwd(ptr(qkv), D3, ptr(o), D, ptr(lse), B, N, H, dh, dh ** -0.5, p, seed, sid, stream())
+            if rc != -2:
+                check(rc, "attn_dh16_train_fwd")
+                ctx.save_for_backward(qkv, lse)
+                return o
         o = Fn.attn_small_fwd(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], B, N, N, H, dh, dh ** -0.5, q_batch_stride=N * D3,
                               kv_batch_stride=N * D3, dropout_p=p, seed=seed, stream_id=sid)
         ctx.save_for_backward(qkv)
-        ctx.cfg = (H, p, seed, sid)
         return o
 
     @staticmethod
     def backward(ctx, do):
-        (qkv,) = ctx.saved_tensors
+        qkv = ctx.saved_tensors[0]
         H, p, seed, sid = ctx.cfg
         B, N, D3 = qkv.shape
         D = D3 // 3
         dh = D // H
         dqkv = torch.empty_like(qkv)
         do2 = do.contiguous().view(B * N, D)
+        if len(ctx.saved_tensors) == 2:                       # the forward ran on the matrix cores: so does the backward
+            lse = ctx.saved_tensors[1]
+            delta = torch.empty_like(lse)
+            check(lib().medp_attn_dh16_train_bwd(ptr(do2), D, ptr(qkv), D3, ptr(lse), ptr(delta), ptr(dqkv), D3, B, N, H, dh, dh ** -0.5, p, seed,
+                                                 sid, stream()), "attn_dh16_train_bwd")
+            return dqkv, None, None, None, None
         base = dqkv.data_ptr()
         check(lib().medp_attn_small_bwd(ptr(do2), D, ptr(qkv), D3, N * D3, qkv.data_ptr() + 4 * D, qkv.data_ptr() + 8 * D, D3, N * D3, base, D3,
                                         base + 4 * D, D3, base + 8 * D, 0, N * D3, B, N, N, H, dh, dh ** -0.5, p, seed, sid, stream()),
