@@ -351,7 +351,11 @@ int medp_embed_inputs_bwd(const float* xs_ts, const float* d_xin, float* partial
 /* psi assembly with special-token overrides (model :53-66) and its backward */
 int medp_psi_assemble_fwd(const float* xs_ts, const float* var_out, const float* tab_out, const float* special, float* psi, int B, int T,
                           int V, int E, void* stream);
-int medp_psi_assemble_bwd(const float* xs_ts, const float* dpsi, float* d_var_out, float* d_tab_out, float* d_special_partial, int B,
+/* backward: d_var_out [V][B*T][E] (zero where a cell was overridden) and, per batch element and SLICE of its cells (S =
+ * medp_psi_assemble_bwd_slices), the partial sums d_tab_partial [B][S][E] (static column) and d_special_partial [B][S][2][E]
+ * (masked / REP cells): the caller adds the slices (a fixed order: deterministic) */
+int medp_psi_assemble_bwd_slices(int B, int T, int V);
+int medp_psi_assemble_bwd(const float* xs_ts, const float* dpsi, float* d_var_out, float* d_tab_partial, float* d_special_partial, int B,
                           int T, int V, int E, void* stream);
 int medp_axis_swap(const float* in, float* out, int B, int A1, int A2, int E, void* stream);
 int medp_add_bcast(const float* a, const float* b, float* out, long long per_batch, int B, int broadcast_b, void* stream);

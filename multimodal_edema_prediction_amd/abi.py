@@ -123,6 +123,7 @@ SIGNATURES = {
     "medp_embed_inputs_bwd_blocks": (I, [I, I, I]),
     "medp_embed_inputs_bwd": (I, [P, P, P, I, I, I, I, I, P]),
     "medp_psi_assemble_fwd": (I, [P, P, P, P, P, I, I, I, I, P]),
+    "medp_psi_assemble_bwd_slices": (I, [I, I, I]),
     "medp_psi_assemble_bwd": (I, [P, P, P, P, P, I, I, I, I, P]),
     "medp_axis_swap": (I, [P, P, I, I, I, I, P]),
     "medp_add_bcast": (I, [P, P, P, LL, I, I, P]),

@@ -301,16 +301,19 @@ __global__ __launch_bounds__(256) void psi_assemble_bwd_kernel(const float* __re
     // scatters d_var and keeps three private float4 sums (static column / masked / REP cells); the NL cell lanes are then added in
     // a fixed order through LDS.  (LDS float atomics, the first form, made the sums depend on the waves' timing; a one-thread-per-
     // sum walk over all cells was deterministic but took 264 us at cfg3.)
+    // One workgroup per (batch element, SLICE of its cells): 64 workgroups walking 4753 cells each left three quarters of the chip
+    // idle for 142 us; the slices' sums are separate output rows, added by the caller in a fixed order.
     extern __shared__ __attribute__((aligned(16))) float red[];          // [NL][3][E]
-    const int b = blockIdx.x, E4 = E >> 2;
+    const int b = blockIdx.x, sl = blockIdx.y, S = gridDim.y, E4 = E >> 2;
     const int NL = 256 / E4;                                              // cell lanes (42 at E = 24)
     const int cl = threadIdx.x / E4, e4 = threadIdx.x - cl * E4;
     const int cells = (T + 1) * (V + 1);
+    const int per = (cells + S - 1) / S, c_lo = sl * per, c_hi = min(cells, c_lo + per);
     float4 acc[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (cl < NL) {
-        for (int cidx = cl; cidx < cells; cidx += NL) {
+        for (int cidx = c_lo + cl; cidx < c_hi; cidx += NL) {
             const int t = cidx / (V + 1), v = cidx - t * (V + 1);
             const int kind = psi_cell_kind(xs, b, t, v, T, V);
             const float4 g = *(const float4*)(dpsi + ((size_t)b * cells + cidx) * E + e4 * 4);
@@ -328,8 +331,8 @@ __global__ __launch_bounds__(256) void psi_assemble_bwd_kernel(const float* __re
         const int k = threadIdx.x / E, e = threadIdx.x - k * E;
         float tot = 0.f;
         for (int l = 0; l < NL; ++l) tot += red[((size_t)l * 3 + k) * E + e];
-        if (k == 0) d_tab[(size_t)b * E + e] = tot;
-        else d_special_part[((size_t)b * 2 + (k - 1)) * E + e] = tot;
+        if (k == 0) d_tab[((size_t)b * S + sl) * E + e] = tot;
+        else d_special_part[(((size_t)b * S + sl) * 2 + (k - 1)) * E + e] = tot;
     }
 }
 
@@ -471,11 +474,16 @@ extern "C" int medp_psi_assemble_fwd(const float* xs_ts, const float* var_out, c
     MEDP_LAUNCH_CHECK("medp_psi_assemble_fwd");
     return 0;
 }
-extern "C" int medp_psi_assemble_bwd(const float* xs_ts, const float* dpsi, float* d_var_out, float* d_tab_out, float* d_special_partial /*[B][2][E]*/,
-                                     int B, int T, int V, int E, void* stream) {
-    MEDP_CHECK_ARG(xs_ts && dpsi && d_var_out && d_tab_out && d_special_partial && E > 0 && E % 4 == 0 && 3 * E <= 256,
+extern "C" int medp_psi_assemble_bwd_slices(int B, int T, int V) {
+    (void)T; (void)V;
+    return max(1, min(16, 512 / max(B, 1)));          // ~512 workgroups
+}
+extern "C" int medp_psi_assemble_bwd(const float* xs_ts, const float* dpsi, float* d_var_out, float* d_tab_partial /*[B][S][E]*/,
+                                     float* d_special_partial /*[B][S][2][E]*/, int B, int T, int V, int E, void* stream) {
+    MEDP_CHECK_ARG(xs_ts && dpsi && d_var_out && d_tab_partial && d_special_partial && E > 0 && E % 4 == 0 && 3 * E <= 256,
                    "psi_assemble_bwd: bad argument");
-    psi_assemble_bwd_kernel<<<B, 256, (size_t)(256 / (E / 4)) * 3 * E * sizeof(float), (hipStream_t)stream>>>(xs_ts, dpsi, d_var_out, d_tab_out, d_special_partial, B, T, V, E);
+    psi_assemble_bwd_kernel<<<dim3(B, medp_psi_assemble_bwd_slices(B, T, V)), 256, (size_t)(256 / (E / 4)) * 3 * E * sizeof(float), (hipStream_t)stream>>>(
+        xs_ts, dpsi, d_var_out, d_tab_partial, d_special_partial, B, T, V, E);
     MEDP_LAUNCH_CHECK("medp_psi_assemble_bwd");
     return 0;
 }

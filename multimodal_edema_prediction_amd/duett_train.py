@@ -136,11 +136,13 @@ class PsiAssembleFn(torch.autograd.Function):
         B, T, V, E, n_special = ctx.cfg
         d = dpsi.contiguous()
         d_var = torch.empty((V, B * T, E), dtype=F32, device=xs.device)
-        d_tab = torch.empty((B, E), dtype=F32, device=xs.device)
-        part = torch.empty((B, 2 * E), dtype=F32, device=xs.device)
-        check(lib().medp_psi_assemble_bwd(ptr(xs), ptr(d), ptr(d_var), ptr(d_tab), ptr(part), B, T, V, E, stream()), "psi_assemble_bwd")
+        S = lib().medp_psi_assemble_bwd_slices(B, T, V)                     # cell slices per batch element (one workgroup each)
+        tab_part = torch.empty((B, S, E), dtype=F32, device=xs.device)
+        part = torch.empty((B * S, 2 * E), dtype=F32, device=xs.device)
+        check(lib().medp_psi_assemble_bwd(ptr(xs), ptr(d), ptr(d_var), ptr(tab_part), ptr(part), B, T, V, E, stream()), "psi_assemble_bwd")
         d_special = torch.zeros((n_special, E), dtype=F32, device=xs.device)
         d_special[:2] = Fn.colsum(part).view(2, E)
+        d_tab = tab_part[:, 0].contiguous() if S == 1 else Fn.colsum(tab_part.transpose(0, 1).reshape(S, B * E)).view(B, E)
         return None, d_var, d_tab, d_special
 
 
