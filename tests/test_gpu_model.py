@@ -304,3 +304,59 @@ def test_pathology_multilabel_loss_value_and_gradient():
             assert maxerr(o[k], ref[k]) < 2e-6, k
         assert maxerr(h2.grad, r2.grad) < 1e-6 and maxerr(h4.grad, r4.grad) < 1e-6
         assert float(r4.grad.abs().max()) > 1e-4          # the check is not vacuous
+
+
+def test_pixel_prefetcher_hands_over_the_batches_in_order():
+    """linear_probe.PixelPrefetcher: the next batch's pixels staged on a copy stream beside the current step, two device buffers."""
+    from multimodal_edema_prediction_amd.linear_probe import PixelPrefetcher
+    host = [torch.full((4, 3, 56, 56), float(i)).pin_memory() for i in range(7)]
+    pre = PixelPrefetcher("cuda", host[0])
+    pre.stage(host[0])
+    sums = []
+    for i in range(7):
+        px = pre.take()
+        if i + 1 < 7:
+            pre.stage(host[i + 1])
+        sums.append(px.double().mean())              # (device work on the taken buffer, enqueued before the next-but-one stage may overwrite it)
+    assert [float(s) for s in sums] == [float(i) for i in range(7)]
+    with pytest.raises(RuntimeError):
+        pre.take()
+    pre.stage(host[0]); pre.stage(host[1])
+    with pytest.raises(RuntimeError):
+        pre.stage(host[2])
+
+
+def test_graphed_probe_step_equals_the_eager_probe_step():
+    """graph_step.GraphedProbeStep (configs[1] as one captured graph) against the eager loop of cxr_linear_training.ipynb: same
+    parameters after the same batches."""
+    from multimodal_edema_prediction_amd.cohort import CohortCfg, make_batch
+    from multimodal_edema_prediction_amd.graph_step import GraphedProbeStep
+    from multimodal_edema_prediction_amd.linear_probe import RadDinoClassifier, masked_bce_with_logits_loss
+    from multimodal_edema_prediction_amd.optim import FusedAdamW
+    dev = torch.device("cuda")
+    ccfg = CohortCfg(n_timesteps=8, n_vars=4, d_static=8, image_size=112, n_labels=7, seed=5)
+    batches = [make_batch(ccfg, 13 * i, 4, mode="teacher") for i in range(3)]
+
+    def build():
+        torch.manual_seed(0)
+        m = RadDinoClassifier("synthetic", num_classes=7, dropout=0.0).to(dev)
+        m.train()
+        return m, FusedAdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3, weight_decay=1e-4)
+
+    me, oe = build()
+    for k in (0, 0, 1, 2, 1):                        # (the captured step's one warm-up step trains on the example batch)
+        b = batches[k]
+        oe.zero_grad()
+        masked_bce_with_logits_loss(me(b["pixel_values"].to(dev)), b["y_multi"].to(dev).float(), b["y_multi_mask"].to(dev).float()).backward()
+        oe.step()
+    mg, og = build()
+    gs = GraphedProbeStep(mg, masked_bce_with_logits_loss, og, batches[0]["pixel_values"], batches[0]["y_multi"], batches[0]["y_multi_mask"], dev,
+                          warmup=1)
+    for k in (0, 1, 2, 1):
+        b = batches[k]
+        out = gs.step(b["pixel_values"], b["y_multi"].float(), b["y_multi_mask"].float())
+    assert np.isfinite(float(out["loss"]))
+    assert og._step == oe._step == 5
+    for (k, a), (_, b2) in zip(me.named_parameters(), mg.named_parameters()):
+        if a.requires_grad:
+            assert float((a - b2).abs().max()) <= 1e-6, k
