@@ -124,7 +124,7 @@ def test_layernorm_fwd_bwd(rows, D):
     assert_close(db, br.grad, 1e-4, 1e-4, "ln db")
 
 
-@pytest.mark.parametrize("rows,D", [(7, 408), (3136 // 8, 2328), (100, 1176)])
+@pytest.mark.parametrize("rows,D", [(7, 408), (3136 // 8, 2328), (100, 1176), (9, 2564), (5, 6216)])      # 6216: the two-pass backward
 def test_scalenorm_fwd_bwd(rows, D):
     x = rnd(rows, D, seed=1)
     g = torch.tensor([1.13])
