@@ -274,6 +274,8 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     abi.require_gpu()
+    if os.environ.get("MEDP_DIST_BACKEND") == "gloo":          # one-GPU rehearsal of N > 1: every rank on the devices there are
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
@@ -349,13 +351,14 @@ def main():
         from multimodal_edema_prediction_amd.graph_step import GraphedStudentStep, GraphedTeacherStep
         os.environ.setdefault("MEDP_PHASE_CHECK", "1")          # report which hardware-queue phase the captured step sits in (graph_step._setup)
         arm = lambda: abi.check(L.medp_gemm_profile_enable(2), "gemm_profile_enable")     # launch clocks ride in the captured GEMMs
+        disarm = lambda: L.medp_gemm_profile_enable(0)                                       # ... and only in those (not in later eager launches)
         try:
             if cfg == "teacher":
                 gstep = GraphedTeacherStep(teacher, loss_fn, opt, dev_pool[0], device, world=world, split=force_pg, pipeline_cxr=pipeline,
-                                           before_capture=arm)
+                                           before_capture=arm, after_capture=disarm)
             else:
                 gstep = GraphedStudentStep(student, teacher, loss_fn, opt, dev_pool[0], device, world=world, split=force_pg,
-                                           pipeline_teacher=pipeline, before_capture=arm)
+                                           pipeline_teacher=pipeline, before_capture=arm, after_capture=disarm)
             gstep.force_collective = force_pg
         except Exception as e:                                 # never seen on one GPU; N > 1 has not run on hardware before the driver's run
             import traceback

@@ -30,7 +30,8 @@ def init_distributed(backend: Optional[str] = None) -> tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # MEDP_DIST_BACKEND=gloo: rehearsal of the N > 1 path with several ranks on ONE GPU (RCCL refuses two ranks on a device)
+            backend = os.environ.get("MEDP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -47,7 +47,7 @@ class _GraphedStep:
     """Capture / replay machinery common to both steps.  Subclasses provide `_frozen_forward()` (frozen part for the NEXT
     batch, on the current stream, returns nothing), `_train_fwd_bwd()` (returns the output dict) and `_hand_over()`."""
 
-    def _setup(self, optimizer, device, world, group, split, pipeline, warmup, before_capture):
+    def _setup(self, optimizer, device, world, group, split, pipeline, warmup, before_capture, after_capture=None):
         self.opt, self.device, self.world, self.group = optimizer, device, world, group
         self.pipeline = bool(pipeline)
         self.epoch = torch.zeros(1, dtype=torch.int32, device=device)
@@ -99,6 +99,8 @@ class _GraphedStep:
         self._pad_streams = [new_stream(device, raw=True) for _ in range(int(os.environ.get("MEDP_PRE_CAPTURE_STREAMS", "3")))]
         self.copy_stream = new_stream(device)
         self._capture()
+        if after_capture is not None:
+            after_capture()                                # (bench.py: stop arming launch clocks — the phase check below launches eagerly too)
         self.phase_log = None
         if self.pipeline and os.environ.get("MEDP_PHASE_CHECK", "0") == "1":
             penalty, t_copy = self._staging_penalty()
@@ -151,7 +153,7 @@ class _GraphedStep:
         ts += [self.opt.dev_step, self.epoch] + list(self._handover_tensors())
         return ts
 
-    def _staging_penalty(self, n: int = 4):
+    def _staging_penalty(self, n: int = 6):
         """(seconds a step takes longer with HOST batches — pinned, staged one call ahead exactly as `step()` does it — than with
         device-resident ones, seconds the pixel copy takes alone).  The steps train: everything they write is snapshotted first and
         restored afterwards (buffers by name: the training path may re-bind them); with more than one rank every rank takes the
@@ -164,14 +166,14 @@ class _GraphedStep:
         host_step, expect = self.opt._step, self._expect
 
         def timed(pool, staged):
-            for i in range(2):
+            ts = []
+            for i in range(n + 3):                             # the median step: the first calls upload the graph / prime the pipeline
+                torch.cuda.synchronize(self.device)
+                t0 = time.perf_counter()
                 self.step(pool[i % 2], pool[(i + 1) % 2], pool[i % 2] if staged else None)
-            torch.cuda.synchronize(self.device)
-            t0 = time.perf_counter()
-            for i in range(n):
-                self.step(pool[i % 2], pool[(i + 1) % 2], pool[i % 2] if staged else None)
-            torch.cuda.synchronize(self.device)
-            return (time.perf_counter() - t0) / n
+                torch.cuda.synchronize(self.device)
+                ts.append(time.perf_counter() - t0)
+            return sorted(ts[3:])[n // 2]
 
         t_res, t_host = timed(dev_b, False), timed(host_b, True)
         px = host_b[0]["pixel_values"]
@@ -258,7 +260,7 @@ class _GraphedStep:
 
 class GraphedTeacherStep(_GraphedStep):
     def __init__(self, teacher, loss_fn, optimizer, example_batch: dict, device, world: int = 1, group=None, warmup: int = 3,
-                 split: bool = False, before_capture=None, pipeline_cxr: bool = False):
+                 split: bool = False, before_capture=None, pipeline_cxr: bool = False, after_capture=None):
         self.teacher, self.loss_fn = teacher, loss_fn
         b = engine._move_lists(example_batch, device)
         # static input buffers; the per-sample tuples the model interface wants are views into the stacked buffers
@@ -280,7 +282,7 @@ class GraphedTeacherStep(_GraphedStep):
         self.y_multi = b["y_multi"].clone().float()
         self.y_mask = b["y_multi_mask"].clone().float()
         engine._set_train_with_frozen_eval(teacher)
-        self._setup(optimizer, device, world, group, split, pipeline_cxr, warmup, before_capture)
+        self._setup(optimizer, device, world, group, split, pipeline_cxr, warmup, before_capture, after_capture)
 
     # ---- the three pieces of a step ----------------------------------------------------------------------------------------
     def _n_frozen_parts(self) -> int:
@@ -401,7 +403,7 @@ class GraphedStudentStep(_GraphedStep):
     encoder + its own frozen DuETT + fusion head, `main_logit` only) runs beside the student's step on batch k."""
 
     def __init__(self, student, teacher, kd_loss_fn, optimizer, example_batch: dict, device, world: int = 1, group=None,
-                 warmup: int = 3, split: bool = False, before_capture=None, pipeline_teacher: bool = True):
+                 warmup: int = 3, split: bool = False, before_capture=None, pipeline_teacher: bool = True, after_capture=None):
         if any(p.requires_grad for p in teacher.parameters()):
             raise ValueError("the KD teacher must be frozen (trainer.py:856-865)")
         self.student, self.teacher, self.loss_fn = student, teacher, kd_loss_fn
@@ -424,7 +426,7 @@ class GraphedStudentStep(_GraphedStep):
         # (in-box A/B: 8.70 ms at the default, 8.47 at 176 / 160, 8.99 at 128)
         prev = lib().medp_gemm_persistent_cap(int(os.environ.get("MEDP_STUDENT_GEMM_CAP", "176")) if pipeline_teacher else 0)
         try:
-            self._setup(optimizer, device, world, group, split, pipeline_teacher, warmup, before_capture)
+            self._setup(optimizer, device, world, group, split, pipeline_teacher, warmup, before_capture, after_capture)
         finally:
             lib().medp_gemm_persistent_cap(prev)
 
