@@ -163,6 +163,14 @@ class Dinov2Backbone(nn.Module):
                 raise ValueError("out16 is a frozen-path argument (the training path returns fp32 tokens with a gradient)")
             tok = forward_training(self, pixel_values)
             return (tok if want_f32 else None), (tok if want_bf16 else None)       # fp32 either way: it carries the gradient
+        if Fn.precision() == "fp32" and layers is None:
+            # the fp32 kernel mode reaches the frozen encoder too (cxr_train.forward_fp32: a parity instrument, not a fast path)
+            from .cxr_train import forward_fp32
+            tok = forward_fp32(self, pixel_values)
+            t16 = None
+            if want_bf16:
+                t16 = tok.to(torch.bfloat16) if out16 is None else out16.copy_(tok)
+            return (tok if want_f32 else None), t16
         w, _, _ = self._prepare()
         px = pixel_values.detach().to(torch.float32).contiguous()
         B, _, H, W = px.shape
@@ -232,6 +240,8 @@ class CXREncoder(nn.Module):
     def forward_bf16(self, pixel_values: torch.Tensor, slot: int = 0, out=None):
         """Build-internal fast path: tokens as bf16 [B, P+1, D], directly consumable by the img_proj GEMM (fp32 tokens with a
         gradient when the encoder is being trained).  `slot` / `out`: see Dinov2Backbone.forward."""
+        if Fn.precision() == "fp32" and out is None and not (any(p.requires_grad for p in self.backbone.parameters()) and torch.is_grad_enabled()):
+            return self.backbone(pixel_values, want_f32=True, want_bf16=False)[0]      # fp32 kernel mode: the tokens stay fp32 all the way
         _, t16 = self.backbone(pixel_values, want_f32=False, want_bf16=True, slot=slot, out16=out)
         return t16
 

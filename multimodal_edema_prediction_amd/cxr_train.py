@@ -218,3 +218,48 @@ def forward_training(backbone, pixel_values: torch.Tensor) -> torch.Tensor:
                             sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"], sd[p + "layer_scale2.lambda1"], c.layer_norm_eps)
     x = A.layer_norm(x, sd["layernorm.weight"], sd["layernorm.bias"], c.layer_norm_eps)
     return x.view(B, S, D)
+
+
+@torch.no_grad()
+def forward_fp32(backbone, pixel_values: torch.Tensor) -> torch.Tensor:
+    """The FROZEN encoder under the fp32 kernel mode (functional.set_precision("fp32")): every GEMM with fp32 operands
+    (`medp_gemm_f32_nt`: bias / exact-erf GELU / LayerScale + residual in its epilogue), LayerNorm in fp32, attention by the fp32
+    small-attention kernel (head dim 64, <= 1536 tokens).  A parity instrument (logits <= 1e-4 against the CPU restatement down to the
+    pixels), ~50x slower than the bf16 path; the patch gather and the position add are data movement done by torch."""
+    c = backbone.cfg
+    sd = {k: v.detach().to(F32) for k, v in backbone.named_parameters()}
+    px = pixel_values.detach().to(F32)
+    B, C, Hh, Ww = px.shape
+    D, H, P = c.hidden_size, c.num_attention_heads, c.patch_size
+    if D != H * 64:
+        raise ValueError("the attention kernel needs head dim 64")
+    gh, gw = Hh // P, Ww // P
+    if 1 + gh * gw > 1536:
+        raise ValueError("fp32 mode: the small-attention kernel takes at most 1536 tokens")
+    cols = px[:, :, :gh * P, :gw * P].unfold(2, P, P).unfold(3, P, P).permute(0, 2, 3, 1, 4, 5).reshape(B * gh * gw, C * P * P).contiguous()
+    patch = Fn.gemm(cols, sd["embeddings.patch_embeddings.projection.weight"].reshape(D, C * P * P).contiguous(),
+                    bias=sd["embeddings.patch_embeddings.projection.bias"]).view(B, gh * gw, D)
+    side = c.image_size // P
+    pos = sd["embeddings.position_embeddings"].reshape(1, -1, D)
+    if not (gh == side and gw == side):
+        pos = PosBicubicFn.apply(sd["embeddings.position_embeddings"], side, gh, gw)
+    x = (torch.cat([sd["embeddings.cls_token"].reshape(1, 1, D).expand(B, 1, D), patch], dim=1) + pos).contiguous()
+    S = x.shape[1]
+    x = x.view(B * S, D)
+    for l in range(c.num_hidden_layers):
+        p = f"encoder.layer.{l}."
+        a = p + "attention.attention."
+        h = Fn.layernorm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], c.layer_norm_eps, out_dtype=F32)
+        wqkv = torch.cat([sd[a + "query.weight"], sd[a + "key.weight"], sd[a + "value.weight"]], 0).contiguous()
+        bqkv = torch.cat([sd[a + "query.bias"], sd[a + "key.bias"], sd[a + "value.bias"]], 0).contiguous()
+        qkv = Fn.gemm(h, wqkv, bias=bqkv).view(B, S, 3 * D)
+        o = Fn.attn_small_fwd(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], B, S, S, H, 64, 0.125, q_batch_stride=S * 3 * D,
+                              kv_batch_stride=S * 3 * D)
+        x = Fn.gemm(o.reshape(B * S, D), sd[p + "attention.output.dense.weight"].contiguous(), bias=sd[p + "attention.output.dense.bias"],
+                    scale=sd[p + "layer_scale1.lambda1"].contiguous(), residual=x)
+        h = Fn.layernorm(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"], c.layer_norm_eps, out_dtype=F32)
+        f = Fn.gemm(h, sd[p + "mlp.fc1.weight"].contiguous(), bias=sd[p + "mlp.fc1.bias"], act=1)
+        x = Fn.gemm(f, sd[p + "mlp.fc2.weight"].contiguous(), bias=sd[p + "mlp.fc2.bias"], scale=sd[p + "layer_scale2.lambda1"].contiguous(),
+                    residual=x)
+    x = Fn.layernorm(x, sd["layernorm.weight"], sd["layernorm.bias"], c.layer_norm_eps, out_dtype=F32)
+    return x.view(B, S, D)

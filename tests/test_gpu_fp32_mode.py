@@ -3,8 +3,8 @@ op-level (trainable) paths with fp32 GEMM operands, checked at §8(d)'s fp32 tol
 rel, gradients ELEMENT-WISE — against the CPU oracle and the reference's fixtures:
   * the student (DuETT trained end to end, BatchNorm batch statistics): the whole model runs op-level, so the comparison is
     end to end, fixtures of the reference's own `train_student_batch` included;
-  * the teacher's fusion head: the CXR encoder has no fp32 form (its bf16 tokens are handed to the oracle as they are), DuETT
-    runs its op-level form in fp32."""
+  * the WHOLE teacher from the pixels on: the frozen CXR encoder runs its fp32 form too (cxr_train.forward_fp32: fp32 GEMMs, fp32
+    small-attention kernel), DuETT its op-level form in fp32."""
 import math
 import os
 import sys
@@ -106,7 +106,7 @@ def test_student_fp32_end_to_end():
     assert n_checked > 100
 
 
-def test_teacher_fusion_head_fp32():
+def test_teacher_fp32_from_the_pixels():
     import test_gpu_model as Tm
     from multimodal_edema_prediction_amd import engine
     from multimodal_edema_prediction_amd.losses_duett import DualPathologyLoss
@@ -119,19 +119,24 @@ def test_teacher_fusion_head_fp32():
     engine._set_train_with_frozen_eval(teacher)
     b = engine._move_lists(tb, DEV)
     with Fn.precision_mode("fp32"):
-        tok16 = teacher.cxr.forward_bf16(b["pixel_values"])
-        out = teacher(b["x_ts"], b["x_static"], b["bin_ends"], b["pixel_values"], _cxr_tokens16=tok16)
+        tok = teacher.cxr.forward_bf16(b["pixel_values"])                 # fp32 tokens in this mode
+        assert tok.dtype == torch.float32
+        out = teacher(b["x_ts"], b["x_static"], b["bin_ends"], b["pixel_values"])
         L = loss_fn(out["img_logits"], out["ts_logits"], out["fusion_logits"], b["y_multi"], b["y_multi_mask"])
         teacher.zero_grad()
         L["total"].backward()
     train = {k: v for k, v in sd.items() if v.is_floating_point() and not k.startswith(("duett.", "cxr."))}
     for v in train.values():
         v.requires_grad_(True)
-    dsd, _ = split_teacher_sd(sd)
+    dsd, vsd = split_teacher_sd(sd)
     xin = duett_ref.feats_to_input((tb["x_ts"], tb["x_static"], list(tb["bin_ends"])), max_len=Tm.T)
     with torch.no_grad():
         ts_tokens = duett_ref.encode(dsd, duett_ref.DuettCfg(d_static_num=Tm.DS, d_time_series_num=Tm.V, n_timesteps=Tm.T), xin)
-    patches = tok16.float().cpu()[:, 1:]                                  # the bf16 CXR tokens exactly as the HIP head received them
+    from oracle import vit_ref
+    with torch.no_grad():
+        _, patches = vit_ref.vit_forward(vsd, vit_ref.VitCfg(), tb["pixel_values"])          # the oracle's own encoder, from the pixels
+    tok_err = float((tok.cpu()[:, 1:] - patches).abs().max())
+    assert tok_err <= 2e-4 * float(patches.abs().max()), tok_err                             # 12 fp32 layers, two summation orders
     ref = fusion_ref.teacher_fusion_forward(sd, ts_tokens, patches, 4)
     Lr = losses_ref.dual_pathology_loss(ref["img_logits"], ref["ts_logits"], ref["fusion_logits"], tb["y_multi"], tb["y_multi_mask"],
                                         torch.ones(Tm.K), None, 0.5, 0.5, 1.0)

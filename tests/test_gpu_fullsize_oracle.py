@@ -72,6 +72,15 @@ def test_teacher_cfg3_full_size_against_oracle():
         assert c > 0.99 and abs(ratio - 1) < 0.1, (k, c, ratio)
         n += 1
     assert n >= 60
+    # the same step under the fp32 kernel mode, the CXR encoder included (cxr_train.forward_fp32): the headline size at fp32 tolerances
+    from multimodal_edema_prediction_amd import functional as Fn
+    with Fn.precision_mode("fp32"), torch.no_grad():
+        out32 = teacher(b["x_ts"], b["x_static"], b["bin_ends"], b["pixel_values"])
+        L32 = DualPathologyLoss(torch.ones(K)).to(DEV)(out32["img_logits"], out32["ts_logits"], out32["fusion_logits"], b["y_multi"], b["y_multi_mask"])
+    for k in ("img_logits", "ts_logits", "fusion_logits", "scaled_correction"):
+        err = float((out32[k].float().cpu() - ref[k].detach()).abs().max())
+        assert err <= 2e-4, ("fp32", k, err)
+    assert abs(float(L32["total"]) - float(Lr["total"])) <= 2e-5 * abs(float(Lr["total"]))
 
 
 def test_student_cfg4_shapes_full_size_against_oracle():
