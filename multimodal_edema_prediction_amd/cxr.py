@@ -197,7 +197,7 @@ class CXREncoder(nn.Module):
     """Mirror of the reference's `CXREncoder` (model file :129-158): same constructor, attributes
     (`backbone`, `d_out`, `return_patches`, `_frozen`), `train()` override and return convention."""
 
-    def __init__(self, model_name: str = "microsoft/rad-dino", freeze: bool = True, return_patches: bool = True,
+    def __init__(self, model_name: str = "microsoft/rad-dino", freeze: bool = True, return_patches: bool = True, *,
                  config: Dinov2Cfg | None = None):
         super().__init__()
         self.backbone = Dinov2Backbone(config)
