@@ -560,7 +560,7 @@ extern "C" int medp_attn_small_bwd(const float* dout, int lddo, const float* q, 
     SmallAttnParams p{q, k, v, ldq, ldkv, ldkv, q_batch_stride, kv_batch_stride, B, Lq, Lk, H, dh, scale, dropout_p, 1.0f / (1.0f - dropout_p), seed, stream_id, medp_rng_epoch_ptr()};
     MEDP_TRY(check(p));
     MEDP_CHECK_ARG(dout && dq && dk && dv, "attn_small_bwd: null gradient buffer");
-    if (fq_eligible(p, dk, dv, lddk, 4) && (dkv_batch_stride & 3) == 0) {
+    if (fq_eligible(p, dk, dv, lddk, lddv) && (dkv_batch_stride & 3) == 0) {     // both gradient row strides: the kernel stores float4 rows of dK AND dV
         const int nch = (Lk + FQ_T - 1) / FQ_T;
         const int nchp = nch <= 1 ? 1 : (nch <= 2 ? 2 : 4);
         const size_t fl = (size_t)(2 * FQ * 64 + 4 * FQ + 16 * FQ * 64 + FQ * nchp * FQ_T) * sizeof(float);

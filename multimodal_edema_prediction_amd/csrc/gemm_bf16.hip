@@ -523,6 +523,7 @@ int launch(const GemmParams& p, hipStream_t stream) {
 namespace {
 struct GemmProfile {
     int mode = 0;
+    int collect_mode = 0;            // the last mode ARMED (1 or 2): what collect() reads — mode 0 only stops the gathering
     std::vector<hipEvent_t> ev;      // mode 1: pairs (start, stop)
     size_t used = 0;
     double flops = 0.0;
@@ -553,13 +554,16 @@ extern "C" int medp_gemm_profile_enable(int mode) {
         g_prof.slot_flops.clear();
     }
     g_prof.mode = mode;      // mode 0 keeps what was gathered for collect()
+    if (mode != 0) g_prof.collect_mode = mode;
     return 0;
 }
 
 extern "C" int medp_gemm_profile_collect(double* total_ms, long long* n_launches, double* total_flops) {
     MEDP_CHECK_ARG(total_ms && n_launches && total_flops, "gemm_profile_collect: null argument");
     double ms = 0.0;
-    if (!g_prof.slot_flops.empty()) {        // in-kernel clocks: the caller has synchronised the device
+    // Dispatch on the mode that was armed last, NOT on "slots exist": slots armed by an earlier mode-2 capture stay alive (their
+    // graph may still be replayed) while a later mode-1 measurement of eager launches must report ITS events.
+    if (g_prof.collect_mode == 2) {          // in-kernel clocks: the caller has synchronised the device
         const size_t n = g_prof.slot_flops.size();
         std::vector<unsigned long long> h(n * 4);
         hipError_t e = hipMemcpy(h.data(), g_prof.slots, n * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);

@@ -43,6 +43,43 @@ def _stacked(v):
     return v if torch.is_tensor(v) else torch.stack(tuple(v))
 
 
+class _TrainSnapshot:
+    """Everything a warm-up step changes that a training run observes: trainable parameters, optimiser state (moments, device and
+    host step counters), module buffers (BatchNorm running statistics, `num_batches_tracked`) and the dropout epoch.  The warm-up
+    iterations torch.cuda.graphs requires are REAL steps on the example batch; `restore()` puts the model back where the caller
+    handed it over, so N graph steps equal N eager steps from the same initial state (tests/test_gpu_pipeline.py)."""
+
+    def __init__(self, params, optimizer, modules, epoch):
+        self.params, self.opt, self.modules, self.epoch = list(params), optimizer, list(modules), epoch
+        with torch.no_grad():
+            self.p = [q.detach().clone() for q in self.params]
+            self.bufs = [(m, n, b.detach().clone()) for m in self.modules for n, b in m.named_buffers()]
+            self.state = {id(q): {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in optimizer.state.get(q, {}).items()}
+                          for q in self.params}
+            self.host_step = int(getattr(optimizer, "_step", 0))
+            self.epoch0 = epoch.detach().clone()
+
+    def restore(self):
+        with torch.no_grad():
+            for q, v in zip(self.params, self.p):
+                q.copy_(v)
+            torch.autograd.graph.increment_version(self.params)
+            for q in self.params:
+                st, old = self.opt.state.get(q, {}), self.state[id(q)]
+                for k, v in st.items():
+                    if torch.is_tensor(v):                 # moments created by the warm-up go back to their initial zeros
+                        v.copy_(old[k]) if k in old else v.zero_()
+            for m, n, v in self.bufs:                      # by NAME (the training path may re-bind buffers), and only what moved: writing a
+                b = m.get_buffer(n)                        # FROZEN module's buffer bumps its version and its prepared weights are rebuilt
+                if not torch.equal(b, v):
+                    b.copy_(v)
+            self.epoch.copy_(self.epoch0)
+            if getattr(self.opt, "dev_step", None) is not None:
+                self.opt.dev_step.fill_(self.host_step)
+            if hasattr(self.opt, "_step"):
+                self.opt._step = self.host_step
+
+
 class _GraphedStep:
     """Capture / replay machinery common to both steps.  Subclasses provide `_frozen_forward()` (frozen part for the NEXT
     batch, on the current stream, returns nothing), `_train_fwd_bwd()` (returns the output dict) and `_hand_over()`."""
@@ -60,7 +97,9 @@ class _GraphedStep:
         # the frozen forward may itself be cut into sub-batches on sibling streams (`_n_frozen_parts`): every one is forked from
         # the step's own stream — a fork nested inside a forked branch crashes hipStreamEndCapture on this runtime
         self.frozen_streams = [new_stream(device) for _ in range(self._n_frozen_parts())] if self.pipeline else []
-        # warm-up on a side stream (allocator pools, lazy workspaces, optimiser state), as torch.cuda.graphs requires
+        # warm-up on a side stream (allocator pools, lazy workspaces, optimiser state), as torch.cuda.graphs requires — real steps
+        # on the example batch, UNDONE afterwards (the run used to start from a model trained `warmup` times on batch 0)
+        snap = _TrainSnapshot(self.params, optimizer, self._stateful_modules(), self.epoch)
         s = new_stream(device)
         s.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(s):
@@ -83,6 +122,8 @@ class _GraphedStep:
         torch.cuda.current_stream(device).wait_stream(s)
         torch.cuda.synchronize(device)
         self._zero_grads()
+        snap.restore()
+        torch.cuda.synchronize(device)
         if before_capture is not None:
             before_capture()
         # Hardware-queue phase.  HIP multiplexes streams over 4 in-order hardware queues, a new stream going to the queue with the
@@ -278,7 +319,7 @@ class GraphedTeacherStep(_GraphedStep):
             # sub-batches of the frozen encoder on sibling streams: the hardware dispatcher then fills the CUs one sub-batch's GEMM
             # leaves idle in its last round of tiles with the other's kernels (MEDP_CXR_PARTS; measured SLOWER on MI355X — 5.83 ms with 2 parts, 7.26 ms with 4 against 5.30 ms — so the default is 1)
             self.cxr_parts = max(1, min(int(os.environ.get("MEDP_CXR_PARTS", "1")), self.pixels.shape[0]))
-            self._expect = None        # id() of the batch whose tokens sit in tok_cur
+            self._expect = None        # the batch (object, held alive: an id() could be reused after a free) whose tokens sit in tok_cur
         self.y_multi = b["y_multi"].clone().float()
         self.y_mask = b["y_multi_mask"].clone().float()
         engine._set_train_with_frozen_eval(teacher)
@@ -326,7 +367,7 @@ class GraphedTeacherStep(_GraphedStep):
         """Pipelined mode: run the CXR encoder for `batch` now, so the next `step(batch, ...)` finds its tokens."""
         with torch.no_grad():
             self.tok_cur.copy_(self.teacher.cxr.forward_bf16(batch["pixel_values"].to(self.device, non_blocking=True)))
-        self._expect = id(batch)
+        self._expect = batch
 
     def load_batch(self, batch: dict) -> None:
         """Copy a batch (host or device) into the static input buffers (async on the current stream)."""
@@ -357,7 +398,7 @@ class GraphedTeacherStep(_GraphedStep):
                 self.stage[k].copy_(_stacked(batch[k]), non_blocking=True)
             self.stage["pixel_values"].copy_(next_batch["pixel_values"], non_blocking=True)
             self.h2d_done.record(self.copy_stream)
-        self._staged = (id(batch), id(next_batch))
+        self._staged = (batch, next_batch)
 
     def _take_staged(self) -> None:
         cur = torch.cuda.current_stream(self.device)
@@ -373,23 +414,23 @@ class GraphedTeacherStep(_GraphedStep):
         if the caller breaks that promise the tokens are recomputed on the spot.
         `after_next` (pipelined mode, HOST batches): the batch after `next_batch`; when given, the host->device copies of the
         next call (`next_batch`'s small tensors, `after_next`'s pixels) are issued on a copy stream now and overlap this replay."""
-        staged = self.pipeline and batch is not None and next_batch is not None and \
-            getattr(self, "_staged", None) == (id(batch), id(next_batch))
+        st = getattr(self, "_staged", None)
+        staged = self.pipeline and batch is not None and next_batch is not None and st is not None and st[0] is batch and st[1] is next_batch
         if staged:
-            if self._expect != id(batch):
+            if self._expect is not batch:
                 self.prime(batch)
             self._take_staged()
-            self._expect = id(next_batch)
+            self._expect = next_batch
         else:
             if batch is not None:
                 self.load_batch(batch)
             if self.pipeline:
-                if batch is not None and self._expect != id(batch):
+                if batch is not None and self._expect is not batch:
                     self.prime(batch)
                 nb = next_batch if next_batch is not None else batch
                 if nb is not None:
                     self.pixels_next.copy_(nb["pixel_values"], non_blocking=True)
-                    self._expect = id(nb)
+                    self._expect = nb
         if self.pipeline and after_next is not None and next_batch is not None and not next_batch["pixel_values"].is_cuda:
             self._stage_h2d(next_batch, after_next)
         else:
@@ -500,7 +541,7 @@ class GraphedStudentStep(_GraphedStep):
         self._load(self.nxt, batch)
         with torch.no_grad():
             self.z_cur.copy_(self._teacher_logit(self.nxt))
-        self._expect = id(batch)
+        self._expect = batch
 
     # ---- host batches: the next call's host->device copies beside this replay (as GraphedTeacherStep) --------------------------
     def _stage_h2d(self, next_batch: dict, after_next: dict) -> None:
@@ -516,7 +557,7 @@ class GraphedStudentStep(_GraphedStep):
             self._load(self.stage, after_next)
             self.stage["y"].copy_(next_batch["y"], non_blocking=True)
             self.h2d_done.record(self.copy_stream)
-        self._staged = (id(next_batch), id(after_next))
+        self._staged = (next_batch, after_next)
 
     def _take_staged(self) -> None:
         cur = torch.cuda.current_stream(self.device)
@@ -534,16 +575,16 @@ class GraphedStudentStep(_GraphedStep):
         teacher step — 98 % of its resident-batch rate this way — the student step stays ~0.85 ms behind its resident-batch time with
         or without the staging: the 38.5-MB pixel copy costs its full duration wherever it is issued (before or after the launch,
         any pool stream, a raw HIP stream), except with GPU_MAX_HW_QUEUES = 3 or 8 where it overlaps (7.8 ms) — DESIGN.md section 6.)"""
-        staged = self.pipeline and batch is not None and next_batch is not None and \
-            getattr(self, "_staged", None) == (id(batch), id(next_batch))
+        st = getattr(self, "_staged", None)
+        staged = self.pipeline and batch is not None and next_batch is not None and st is not None and st[0] is batch and st[1] is next_batch
         if staged:
-            if self._expect != id(batch):
+            if self._expect is not batch:
                 self.prime(batch)
             self._take_staged()
-            self._expect = id(next_batch)
+            self._expect = next_batch
         else:
             if batch is not None:
-                if self.pipeline and self._expect != id(batch):
+                if self.pipeline and self._expect is not batch:
                     self.prime(batch)
                 self._load(self.cur, batch, with_pixels=not self.pipeline)
                 self.y.copy_(batch["y"], non_blocking=True)
@@ -551,7 +592,7 @@ class GraphedStudentStep(_GraphedStep):
                 nb = next_batch if next_batch is not None else batch
                 if nb is not None:
                     self._load(self.nxt, nb)
-                    self._expect = id(nb)
+                    self._expect = nb
         if self.pipeline and after_next is not None and next_batch is not None and not next_batch["pixel_values"].is_cuda:
             self._stage_h2d(next_batch, after_next)
         else:
@@ -572,6 +613,7 @@ class GraphedProbeStep:
         self.mask = example_mask.to(device).float().clone()
         self.epoch = torch.zeros(1, dtype=torch.int32, device=device)
         check(lib().medp_rng_set_epoch_ptr(ptr(self.epoch)), "rng_set_epoch_ptr")
+        snap = _TrainSnapshot([p for g in optimizer.param_groups for p in g["params"] if p.requires_grad], optimizer, [probe], self.epoch)
         s = new_stream(device)
         s.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(s):
@@ -580,6 +622,8 @@ class GraphedProbeStep:
         torch.cuda.current_stream(device).wait_stream(s)
         torch.cuda.synchronize(device)
         self.opt.zero_grad(set_to_none=True)
+        snap.restore()                                      # the warm-up steps trained: put the head and its optimiser state back
+        torch.cuda.synchronize(device)
         if before_capture is not None:
             before_capture()
         self.g = torch.cuda.CUDAGraph()

@@ -9,8 +9,11 @@ out of scope; the cohort comes from cohort.py (the reference's own smoke-test re
     torchrun --nproc-per-node N -m multimodal_edema_prediction_amd.train_synthetic teacher ...      (one rank per GPU, RCCL)
 
 Defaults follow training_duett/run.py (lr 8e-5, weight decay 5e-2, warm-up 300 steps, backbone / query LR x0.2, patience 5,
-perceiver dropout 0.2, d_latent 256, 4 heads, head_hidden 128).  `--graph` replays the captured-graph step (graph_step.py)
-instead of the eager engine step; both run the same arithmetic.
+perceiver dropout 0.2, d_latent 256, 4 heads, head_hidden 128).  The step is the captured-graph step (graph_step.py) by default —
+the eager engine step is host-bound at ~1/3 of its rate; `--eager` runs `engine.py` from Python instead.  Both run the same
+arithmetic from the same initial state (the graph class undoes its warm-up steps; tests/test_gpu_pipeline.py).  The loop hands the
+graph step the NEXT batch too (one-batch look-ahead), so the frozen part of batch k+1 runs beside the step of batch k and no
+encoder forward is run twice.
 """
 from __future__ import annotations
 
@@ -57,7 +60,8 @@ def _common(ap: argparse.ArgumentParser) -> None:
     ap.add_argument("--transformer_dropout", type=float, default=0.0)
     ap.add_argument("--aug_noise", type=float, default=0.0)
     ap.add_argument("--aug_mask", type=float, default=0.0)
-    ap.add_argument("--graph", action="store_true", help="replay the captured HIP-graph step instead of the eager engine step")
+    ap.add_argument("--graph", action="store_true", help="(default) replay the captured HIP-graph step; kept for old command lines")
+    ap.add_argument("--eager", action="store_true", help="run the eager engine step (engine.py from Python) instead of the captured-graph step")
     ap.add_argument("--learnable_labels", action="store_true", help="labels depend on the inputs (so that AUROC moves)")
 
 
@@ -85,7 +89,28 @@ def parse_args(argv=None) -> argparse.Namespace:
     s.add_argument("--kd_name", default="vanilla_kl")
     s.add_argument("--kd_T", type=float, default=4.0)
     s.add_argument("--kd_alpha", type=float, default=0.5)
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    # graph mode is the default; the eager engine step stays for --eager and for what the captured step does not carry
+    # (the aux residual KL of engine.py:149-165 is an engine extra, off by default)
+    args.graph = not args.eager and float(getattr(args, "aux_residual_alpha", 0.0)) == 0.0
+    return args
+
+
+def _with_next(loader, limit: int = 0):
+    """(batch, next batch or None) pairs: the graph step runs the frozen part of the NEXT batch beside this batch's step."""
+    it = iter(loader)
+    cur = next(it, None)
+    n = 0
+    while cur is not None:
+        n += 1
+        nxt = None if (limit and n >= limit) else next(it, None)
+        yield cur, nxt
+        cur = nxt
+
+
+def _same_size(a: dict, b: dict | None) -> dict | None:
+    """The captured step has static shapes: a ragged last batch is neither trained on by the graph nor announced to it."""
+    return b if (b is not None and b["y"].shape[0] == a["y"].shape[0]) else None
 
 
 # ------------------------------------------------------------------------------------------------------------------ plumbing
@@ -166,17 +191,19 @@ def train_teacher(args) -> dict:
     for epoch in range(1, args.epochs + 1):
         loader = make_loader(train_ds, args.batch_size, True, args.num_workers, "teacher", rank, world, epoch_seed=args.seed + epoch)
         run = {"loss": 0.0, "img": 0.0, "ts": 0.0, "fus": 0.0, "n": 0}
-        for step, batch in enumerate(loader):
-            if args.limit_batches and step >= args.limit_batches:
-                break
-            if args.graph:
-                if gstep is None:
-                    from .graph_step import GraphedTeacherStep
-                    gstep = GraphedTeacherStep(teacher, loss_fn, opt, batch, device, world=world,
-                                               pipeline_cxr=not args.unfreeze_cxr and args.perceiver_type != "dual")
-                out = gstep.step(batch)
+        for step, (batch, nxt) in enumerate(_with_next(loader, args.limit_batches)):
+            if args.graph and gstep is None:
+                from .graph_step import GraphedTeacherStep
+                gstep = GraphedTeacherStep(teacher, loss_fn, opt, batch, device, world=world,
+                                           pipeline_cxr=not args.unfreeze_cxr and args.perceiver_type != "dual")
+                graph_bs = batch["y"].shape[0]
+            if args.graph and batch["y"].shape[0] == graph_bs:
+                out = gstep.step(batch, _same_size(batch, nxt))
                 out = {"loss": out["loss"], "img_total": out["img_total"], "ts_total": out["ts_total"], "fus_total": out["fus_total"]}
             else:
+                if args.graph:         # (the training loader drops the ragged last batch, trainer.py:54-60: not reached from it)
+                    raise RuntimeError("captured-graph step: the loader produced a batch of a different size than the captured one; "
+                                       "the graph's optimiser table must not be rebuilt by an eager step in between — use --eager")
                 out = engine.train_teacher_dual_pathology_batch(batch, teacher, loss_fn, opt, device, aux_residual_alpha=args.aux_residual_alpha)
             sched.step()
             bs = batch["y"].shape[0]
@@ -257,15 +284,17 @@ def train_student(args) -> dict:
     for epoch in range(1, args.epochs + 1):
         loader = make_loader(train_ds, args.batch_size, True, args.num_workers, "teacher", rank, world, epoch_seed=args.seed + epoch)
         run = {"loss": 0.0, "bce": 0.0, "kd": 0.0, "n": 0}
-        for step, batch in enumerate(loader):
-            if args.limit_batches and step >= args.limit_batches:
-                break
-            if args.graph:
-                if gstep is None:
-                    from .graph_step import GraphedStudentStep
-                    gstep = GraphedStudentStep(student, teacher, kd, opt, batch, device, world=world, pipeline_teacher=False)
-                out = gstep.step(batch)
+        for step, (batch, nxt) in enumerate(_with_next(loader, args.limit_batches)):
+            if args.graph and gstep is None:
+                from .graph_step import GraphedStudentStep
+                gstep = GraphedStudentStep(student, teacher, kd, opt, batch, device, world=world, pipeline_teacher=True)
+                graph_bs = batch["y"].shape[0]
+            if args.graph and batch["y"].shape[0] == graph_bs:
+                out = gstep.step(batch, _same_size(batch, nxt))
             else:
+                if args.graph:         # (the training loader drops the ragged last batch, trainer.py:54-60: not reached from it)
+                    raise RuntimeError("captured-graph step: the loader produced a batch of a different size than the captured one; "
+                                       "the graph's optimiser table must not be rebuilt by an eager step in between — use --eager")
                 out = engine.train_student_batch(batch, batch, student, teacher, kd, opt, device)
             sched.step()
             bs = batch["y"].shape[0]

@@ -107,12 +107,14 @@ def run_parity(lr=5e-4, n_steps=200, n_train_b=16, n_eval_b=32):
 
 
 def test_trained_teacher_auroc_matches_cpu_oracle():
-    # lr / pool from tools/auroc_sweep.py (gpurun_out/r2_auroc_sweep.log): at 5e-5 over 512 training items the two runs stay one
-    # trajectory (max per-label difference 0.0009); at 5e-4 over 256 items the run memorises the pool, AdamW amplifies bf16
-    # rounding into different minima and the held-out AUROCs of BOTH runs are noise around 0.5 (differences up to 0.47)
+    # The contract point is the REFERENCE'S OWN learning rate, 8e-5 (run.py; ADVICE r2: round 2 asserted at 5e-5).  The sweep
+    # (tools/auroc_sweep.py, profiles/r02_auroc_sweep.txt) brackets it: over 512 training items the two runs stay one trajectory at
+    # 5e-5 (max per-label difference 0.0009) and at 1e-4 (0.0042); at 2e-4 / 5e-4 over 256 items the run memorises the pool, AdamW
+    # amplifies bf16 rounding into different minima and the held-out AUROCs of BOTH runs are noise around 0.5 (differences 0.15 / 0.47)
+    # — the bound holds on the low-LR side up to ~1e-4, BASELINE.md states that range.
     # 1536 held-out items (the contract asks for >= 512): at the cohort's 2 % prevalences 512 items hold one or two positives of
     # the rare labels, an AUROC that moves by 0.002 per rank of a single item — noise, not parity
-    r = run_parity(lr=5e-5, n_steps=200, n_train_b=32, n_eval_b=96)          # 512 training items, 1536 held-out items
+    r = run_parity(lr=8e-5, n_steps=200, n_train_b=32, n_eval_b=96)          # 512 training items, 1536 held-out items
     hl, rl, a_hip, a_ref = r["hip_losses"], r["ref_losses"], r["a_hip"], r["a_ref"]
     print("per-label AUROC hip", np.round(a_hip, 4), "oracle", np.round(a_ref, 4), "max |logit diff|",
           float(np.abs(r["hip_logits"] - r["ref_logits"]).max()), "loss first/last", rl[:3], rl[-3:])

@@ -260,17 +260,17 @@ def test_graphed_step_equals_eager_step(tbatch):
     loss_fn = DualPathologyLoss(torch.ones(K), None, 0.5, 0.5, 1.0).to(DEV)
     te = build_teacher()
     oe = FusedAdamW(make_param_groups(te, 8e-5), weight_decay=5e-2)
-    eager_losses = [engine.train_teacher_dual_pathology_batch(tbatch, te, loss_fn, oe, torch.device(DEV))["loss"] for _ in range(6)]
+    eager_losses = [engine.train_teacher_dual_pathology_batch(tbatch, te, loss_fn, oe, torch.device(DEV))["loss"] for _ in range(3)]
     tg = build_teacher()
     og = FusedAdamW(make_param_groups(tg, 8e-5), weight_decay=5e-2)
-    gs = GraphedTeacherStep(tg, loss_fn, og, tbatch, torch.device(DEV), warmup=3)       # 3 real steps happen during warm-up
+    gs = GraphedTeacherStep(tg, loss_fn, og, tbatch, torch.device(DEV), warmup=3)       # the 3 warm-up steps are undone before the capture
     graph_losses = [float(gs.step(tbatch)["loss"].item()) for _ in range(3)]
-    # eager steps 4..6 vs the three replays (steps 4..6 of the graphed run)
-    np.testing.assert_allclose(graph_losses, eager_losses[3:], rtol=1e-5, atol=1e-6)
+    # eager steps 1..3 vs the three replays: the same initial state, no warm-up offset
+    np.testing.assert_allclose(graph_losses, eager_losses, rtol=1e-5, atol=1e-6)
     for (k, a), (_, b) in zip(te.named_parameters(), tg.named_parameters()):
         if a.requires_grad:
             assert float((a - b).abs().max()) <= 1e-6, k
-    assert og._step == oe._step == 6
+    assert og._step == oe._step == 3
 
 
 def test_pathology_multilabel_loss_value_and_gradient():
@@ -344,7 +344,7 @@ def test_graphed_probe_step_equals_the_eager_probe_step():
         return m, FusedAdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3, weight_decay=1e-4)
 
     me, oe = build()
-    for k in (0, 0, 1, 2, 1):                        # (the captured step's one warm-up step trains on the example batch)
+    for k in (0, 1, 2, 1):                           # (the captured step's warm-up step on the example batch is undone before the capture)
         b = batches[k]
         oe.zero_grad()
         masked_bce_with_logits_loss(me(b["pixel_values"].to(dev)), b["y_multi"].to(dev).float(), b["y_multi_mask"].to(dev).float()).backward()
@@ -356,7 +356,7 @@ def test_graphed_probe_step_equals_the_eager_probe_step():
         b = batches[k]
         out = gs.step(b["pixel_values"], b["y_multi"].float(), b["y_multi_mask"].float())
     assert np.isfinite(float(out["loss"]))
-    assert og._step == oe._step == 5
+    assert og._step == oe._step == 4
     for (k, a), (_, b2) in zip(me.named_parameters(), mg.named_parameters()):
         if a.requires_grad:
             assert float((a - b2).abs().max()) <= 1e-6, k

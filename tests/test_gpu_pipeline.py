@@ -91,11 +91,10 @@ def test_graph_step_with_scheduler_matches_eager_without_host_sync():
     loss_fn = DualPathologyLoss(torch.ones(T.K), None, 0.5, 0.5, 1.0).to(dev)
     batch = T.make_batch(T.CCFG, T.META["teacher_batch_start"], T.B, mode="teacher")
     N, W = 12, 2
-    # W constant-rate steps first (the graph class's warm-up iterations are real steps), THEN the schedule starts in both runs
+    # the graph class's W warm-up iterations are undone before the capture (graph_step._TrainSnapshot): BOTH runs start from the
+    # initial state, no warm-up offset on the eager side
     te = T.build_teacher()
     oe = FusedAdamW(make_param_groups(te, 8e-3), weight_decay=5e-2)
-    for _ in range(W):
-        engine.train_teacher_dual_pathology_batch(batch, te, loss_fn, oe, dev)
     se = make_scheduler(oe, total_steps=100, lr=8e-3, warmup_steps=10)
     eager_loss, eager_lr = [], []
     for _ in range(N):
@@ -119,7 +118,7 @@ def test_graph_step_with_scheduler_matches_eager_without_host_sync():
     for (k, a), (_, b) in zip(te.named_parameters(), tg.named_parameters()):
         if a.requires_grad:
             assert float((a - b).abs().max()) <= 2e-6, k
-    assert og._step == oe._step == N + W
+    assert og._step == oe._step == N
 
 
 def test_split_step_leaves_unused_parameters_alone():

@@ -47,18 +47,18 @@ def test_graphed_student_step_equals_eager_engine_step():
     kd = StudentKDLoss("vanilla_kl", 4.0, 0.5)
     se, te = _build(dev)
     oe = FusedAdamW([p for p in se.parameters() if p.requires_grad], lr=1e-3, weight_decay=5e-2)
-    eager = [engine.train_student_batch(batch, batch, se, te, kd, oe, dev) for _ in range(5)]
+    eager = [engine.train_student_batch(batch, batch, se, te, kd, oe, dev) for _ in range(3)]       # the graph class undoes its 2 warm-up steps
     sg, tg = _build(dev)
     og = FusedAdamW([p for p in sg.parameters() if p.requires_grad], lr=1e-3, weight_decay=5e-2)
     gs = GraphedStudentStep(sg, tg, kd, og, batch, dev, warmup=2, pipeline_teacher=False)
     outs = [gs.step(batch) for _ in range(3)]
     g_losses = [float(o["loss"].item()) for o in [outs[-1]]]          # `out` tensors are static: read the last replay's
-    assert abs(g_losses[0] - eager[4]["loss"]) <= 2e-5 * abs(eager[4]["loss"]) + 1e-6
+    assert abs(g_losses[0] - eager[2]["loss"]) <= 2e-5 * abs(eager[2]["loss"]) + 1e-6
     for (k, a), (_, b) in zip(se.named_parameters(), sg.named_parameters()):
         assert float((a - b).abs().max()) <= 2e-6, k
     for (k, a), (_, b) in zip(se.named_buffers(), sg.named_buffers()):
         assert float((a.float() - b.float()).abs().max()) <= 1e-6, k        # BatchNorm running statistics / counters
-    assert og._step == oe._step == 5
+    assert og._step == oe._step == 3
     # never-used SSL heads: no gradient, no optimiser state (find_unused_parameters semantics)
     named = dict(sg.named_parameters())
     for k, p in named.items():

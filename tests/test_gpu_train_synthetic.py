@@ -20,7 +20,7 @@ TINY = ["--n_timesteps", "32", "--n_vars", "16", "--image_size", "112", "--n_tra
 def test_teacher_driver_trains_saves_and_reloads(tmp_path, graph):
     from multimodal_edema_prediction_amd import checkpoint, train_synthetic
     d = str(tmp_path / "t")
-    out = train_synthetic.main(["teacher", "--ckpt_dir", d, "--epochs", "2", "--freeze_duett"] + TINY + (["--graph"] if graph else []))
+    out = train_synthetic.main(["teacher", "--ckpt_dir", d, "--epochs", "2", "--freeze_duett"] + TINY + ([] if graph else ["--eager"]))
     assert len(out["history"]) == 2 and out["history"][0]["improved"]
     assert math.isfinite(out["history"][-1]["train_loss"]) and 0.0 <= out["best_val_auroc"] <= 1.0
     assert out["test"]["n"] == 48 and len(out["test"]["per_label"]) == 7
