@@ -11,11 +11,12 @@
     under no-grad + DuETT student trained end to end (BatchNorm batch statistics) + StudentKDLoss, 35.6 MB gradient exchange.
 --config probe (configs[1]): CXR-encoder linear probe (cxr_linear_training.ipynb:396-437), head-only training.
 
-One step = the whole step function: host->device transfer of the batch, `feats_to_input` (device kernel), forward of every
-encoder, loss, backward of every trainable parameter, gradient all-reduce when N > 1, optimiser step, scheduler step.
-`value` is the PCIe-INCLUSIVE rate ("around the full step incl. H2D of the batch"): batches sit in pinned host
-memory, as a DataLoader(pin_memory=True) hands them over, and are staged one call ahead on a copy stream.  The rate with the
-batches already resident in HBM is measured right after the timed region and reported as `config.resident_batch_samples_per_s`.
+One step = the whole step function: `feats_to_input` (device kernel), forward of every encoder, loss, backward of every trainable
+parameter, gradient all-reduce when N > 1, optimiser step, scheduler step.
+`value` is the rate with the batches RESIDENT IN HBM when the timed region starts (the driver's contract).  The PCIe-INCLUSIVE rate
+(batches in pinned host memory, as a DataLoader(pin_memory=True) hands them over, staged one call ahead on a copy
+stream) is measured right after the timed region and reported as `config.pcie_inclusive_samples_per_s`; `--host-batches` swaps the two.
+`ms_per_step_median`: per-step HIP events over max(steps, 50) further steps.
 
 N > 1: `python bench.py --gpus N` starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process
 before any GPU call and relays rank 0's JSON line; under torch.distributed.run (RANK set) it is one rank per GPU over RCCL.
@@ -58,7 +59,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="graph mode: run the frozen part inside its own batch's step instead of one batch ahead")
-    ap.add_argument("--resident", action="store_true", help="A/B: time the step on HBM-resident batches (a side measurement; the line says so)")
+    ap.add_argument("--resident", action="store_true", help="(default since round 3; kept for old command lines) time the step on HBM-resident batches")
+    ap.add_argument("--host-batches", action="store_true",
+                    help="side measurement: time the PCIe-INCLUSIVE step (batches in pinned host memory, staged one call ahead) as `value`")
     ap.add_argument("--eager", action="store_true", help="run the step eagerly from Python (engine.py) instead of replaying captured HIP graphs")
     ap.add_argument("--unfreeze-cxr", action="store_true",
                     help="train the CXR encoder too (run.py --unfreeze_cxr; SURVEY 8f1): a side measurement, never the contract line")
@@ -133,29 +136,29 @@ def build_student(T, V, DS, device, seed=1):
     return StudentModel(backbone, pool="mean", head_hidden=128, head_dropout=0.1).to(device)
 
 
-def cpu_baseline(config, model, teacher, ccfg, K, batch_cpu, target_seconds=15.0):
-    """The CPU oracle (oracle/step_ref.py) on the host cores, same step, bounded sample."""
+def cpu_baseline(config, model, teacher, ccfg, K, batch_cpu, small_batch_cpu, timed_steps=3, warm_steps=2):
+    """The CPU oracle (oracle/step_ref.py) on the host cores — SURVEY.md §8(d): the same step at the same batch, `n` = all cores
+    this job may use (2 warm-up + 3 timed steps, ~30 s) and `n` = 1 beside it (one step of a 4-sample batch: a one-core step of
+    the full batch would take minutes)."""
     import torch
     from oracle import duett_ref, optim_ref, step_ref, vit_ref
     cores = usable_cores()
-    torch.set_num_threads(cores)
     dcfg = duett_ref.DuettCfg(d_static_num=ccfg.d_static, d_time_series_num=ccfg.n_vars, n_timesteps=ccfg.n_timesteps)
     vcfg = vit_ref.VitCfg()
     lrs = optim_ref.group_lrs(8e-5)
     lr_of = lambda name: lrs[optim_ref.param_group_of(name)] * 1e-4
     state = {"step": 0, "m": {}, "v": {}}
-    n = batch_cpu["y"].shape[0]
     tsd = {k: v.detach().float().cpu().clone() for k, v in teacher.state_dict().items()}
     if config == "teacher":
-        run = lambda: step_ref.teacher_step(tsd, dcfg, vcfg, batch_cpu, state, lr_of)
+        run = lambda bt: step_ref.teacher_step(tsd, dcfg, vcfg, bt, state, lr_of)
         what = "teacher steps"
     elif config == "student":
         ssd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
 
-        def run():
+        def run(bt):
             with torch.no_grad():
-                z_t = step_ref.teacher_forward(tsd, dcfg, vcfg, batch_cpu)["main_logit"]
-            step_ref.student_step(ssd, dcfg, batch_cpu, z_t, state, lambda name: 8e-5 * 1e-4)
+                z_t = step_ref.teacher_forward(tsd, dcfg, vcfg, bt)["main_logit"]
+            step_ref.student_step(ssd, dcfg, bt, z_t, state, lambda name: 8e-5 * 1e-4)
         what = "student-KD steps (frozen teacher forward + student forward/backward/AdamW)"
     else:
         vsd = {k[len("encoder.backbone."):]: v.detach().float().cpu().clone() for k, v in model.state_dict().items()
@@ -164,80 +167,100 @@ def cpu_baseline(config, model, teacher, ccfg, K, batch_cpu, target_seconds=15.0
         bb = model.classifier[1].bias.detach().float().cpu().clone().requires_grad_(True)
         from oracle import losses_ref
 
-        def run():
+        def run(bt):
             with torch.no_grad():
-                cls, _ = vit_ref.vit_forward(vsd, vcfg, batch_cpu["pixel_values"])
-            loss = losses_ref.masked_bce_global(torch.nn.functional.linear(cls, W, bb), batch_cpu["y_multi"], batch_cpu["y_multi_mask"])
+                cls, _ = vit_ref.vit_forward(vsd, vcfg, bt["pixel_values"])
+            loss = losses_ref.masked_bce_global(torch.nn.functional.linear(cls, W, bb), bt["y_multi"], bt["y_multi_mask"])
             loss.backward()
         what = "linear-probe steps (frozen ViT forward + head forward/backward)"
+    n, n1 = batch_cpu["y"].shape[0], small_batch_cpu["y"].shape[0]
+    torch.set_num_threads(cores)
+    for _ in range(warm_steps):
+        run(batch_cpu)
     t0 = time.perf_counter()
-    run()                                                            # warm-up (thread pools, allocator)
-    warm = time.perf_counter() - t0
-    steps = max(1, min(64, int((target_seconds - warm) / max(warm, 1e-3))))      # ~15 s of CPU work
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        run()
+    for _ in range(timed_steps):
+        run(batch_cpu)
     dt = time.perf_counter() - t0
-    return {"value": round(n * steps / dt, 3), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} {what} of batch {n} (same shapes: 224x224 CXR, T={ccfg.n_timesteps}, V={ccfg.n_vars}) "
-                      f"through the fp32 CPU oracle, torch.set_num_threads({cores}), {dt:.1f} s"}
+    torch.set_num_threads(1)
+    t0 = time.perf_counter()
+    run(small_batch_cpu)
+    dt1 = time.perf_counter() - t0
+    torch.set_num_threads(cores)
+    return {"value": round(n * timed_steps / dt, 3), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{warm_steps} warm-up + {timed_steps} timed {what} of batch {n} (the step's own shapes: {ccfg.image_size}x{ccfg.image_size} CXR, "
+                      f"T={ccfg.n_timesteps}, V={ccfg.n_vars}) through the fp32 CPU oracle, torch.set_num_threads({cores}), {dt:.1f} s timed",
+            "one_core": {"value": round(n1 / dt1, 3), "unit": "samples/s", "cores": 1,
+                         "sample": f"1 step of batch {n1}, torch.set_num_threads(1), {dt1:.1f} s"}}
 
 
 def hbm_kernel_table(B, T, V, device, duett=None):
     """The HBM-bound kernels SURVEY.md §8(d) asks to be reported one by one: algorithmic bytes (each operand read once, each result
-    written once), live HIP-event time of isolated launches at the step's shapes, fraction of 8 TB/s."""
+    written once) and live HIP-event times of isolated launches at the step's shapes — COLD: the launches rotate over enough operand
+    sets that more than 256 MiB (the Infinity Cache) pass between two uses of a buffer, which is what a kernel sees inside the step;
+    WARM (one operand set repeated: it fits the Infinity Cache) is reported beside it, labelled.  The fraction of 8 TB/s is the cold one."""
     import torch
     from multimodal_edema_prediction_amd import functional as Fn
     from multimodal_edema_prediction_amd.abi import check, lib, ptr, stream
 
-    def timeit(fn, iters=50, warm=5):
-        for _ in range(warm):
-            fn()
+    def timeit(fn, nsets, iters=48, warm=6):
+        for i in range(warm):
+            fn(i % nsets)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(iters):
-            fn()
+        for i in range(iters):
+            fn(i % nsets)
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / iters * 1e3       # us
 
+    def both(make, run, set_bytes):
+        """make(i) -> operand set; run(set); set_bytes = device bytes one set occupies"""
+        n = int(max(3, min(16, (300 << 20) // max(set_bytes, 1) + 2)))
+        sets = [make(i) for i in range(n)]
+        cold = timeit(lambda i: run(sets[i]), n)
+        warm_ = timeit(lambda i: run(sets[0]), 1)
+        del sets
+        return cold, warm_, n
+
     rows = []
     E, T1, V1 = 24, T + 1, V + 1
-    psi = torch.randn(B, T1, V1, E, device=device)
-    out = torch.empty(B, V1, T1, E, device=device)
-    us = timeit(lambda: check(lib().medp_axis_swap(ptr(psi), ptr(out), B, T1, V1, E, stream()), "axis_swap"))
-    rows.append(("axis_swap_kernel (psi <-> event view, fp32)", 2 * psi.numel() * 4, us))
+    psi_elems = B * T1 * V1 * E
+    c, w_, n = both(lambda i: (torch.randn(B, T1, V1, E, device=device), torch.empty(B, V1, T1, E, device=device)),
+                    lambda a: check(lib().medp_axis_swap(ptr(a[0]), ptr(a[1]), B, T1, V1, E, stream()), "axis_swap"), psi_elems * 8)
+    rows.append(("axis_swap_kernel (psi <-> event view, fp32)", 2 * psi_elems * 4, c, w_, n))
+    g1 = torch.ones(1, device=device)
     for name, rows_n, D in (("scalenorm (time view rows, fp32 -> bf16)", B * T1, V1 * E), ("scalenorm (event view rows, fp32 -> bf16)", B * V1, T1 * E)):
-        x = torch.randn(rows_n, D, device=device)
-        g = torch.ones(1, device=device)
-        us = timeit(lambda: Fn.scalenorm(x, g))
-        rows.append((name, x.numel() * 6, us))
+        c, w_, n = both(lambda i: torch.randn(rows_n, D, device=device), lambda x: Fn.scalenorm(x, g1), rows_n * D * 6)
+        rows.append((name, rows_n * D * 6, c, w_, n))
     M = B * 257
-    x = torch.randn(M, 768, device=device)
-    w, b = torch.ones(768, device=device), torch.zeros(768, device=device)
-    us = timeit(lambda: Fn.layernorm(x, w, b, 1e-6))
-    rows.append(("layernorm_fwd_reg_kernel (ViT tokens, fp32 -> bf16)", x.numel() * 6, us))
+    lw, lb = torch.ones(768, device=device), torch.zeros(768, device=device)
+    c, w_, n = both(lambda i: torch.randn(M, 768, device=device), lambda x: Fn.layernorm(x, lw, lb, 1e-6), M * 768 * 6)
+    rows.append(("layernorm_fwd_reg_kernel (ViT tokens, fp32 -> bf16)", M * 768 * 6, c, w_, n))
     if duett is not None:                      # the fused DuETT front end (csrc/duett.hip), at the step's shapes
-        psi_elems = B * T1 * V1 * E
-        xs_static, xs_ts, xs_times = torch.randn(B, 8, device=device), torch.zeros(B, T, 2 * V + 1, device=device), torch.rand(B, T, device=device)
-        xs_ts[:, :, :V] = torch.randn(B, T, V, device=device)
-        xs_ts[:, :, V:2 * V] = torch.randint(0, 4, (B, T, V), device=device).float()
         w = duett._prepare()[0]
-        xe, h = torch.empty(psi_elems, device=device), torch.empty(psi_elems, device=device, dtype=torch.bfloat16)
-        temb, tab = torch.empty(psi_elems, device=device), torch.empty(B * E, device=device)
-        emb = lambda st: check(lib().medp_duett_embed_fwd(ctypes.byref(w), ptr(xs_static), ptr(xs_ts), ptr(xs_times), B, T, ptr(xe), ptr(h),
-                                                          ptr(temb), None, ptr(tab), st, stream()), "duett_embed_fwd")
-        us = timeit(lambda: emb(1))
+
+        def mk(i):
+            xs_ts = torch.zeros(B, T, 2 * V + 1, device=device)
+            xs_ts[:, :, :V] = torch.randn(B, T, V, device=device)
+            xs_ts[:, :, V:2 * V] = torch.randint(0, 4, (B, T, V), device=device).float()
+            return {"st": torch.randn(B, 8, device=device), "ts": xs_ts, "tm": torch.rand(B, T, device=device),
+                    "xe": torch.empty(psi_elems, device=device), "h": torch.empty(psi_elems, device=device, dtype=torch.bfloat16),
+                    "temb": torch.empty(psi_elems, device=device), "tab": torch.empty(B * E, device=device),
+                    "psi": torch.empty(psi_elems, device=device), "rn": torch.rand(B * V1, device=device)}
+        emb = lambda a, st: check(lib().medp_duett_embed_fwd(ctypes.byref(w), ptr(a["st"]), ptr(a["ts"]), ptr(a["tm"]), B, T, ptr(a["xe"]), ptr(a["h"]),
+                                                             ptr(a["temb"]), None, ptr(a["tab"]), st, stream()), "duett_embed_fwd")
+        set_bytes = psi_elems * (4 + 2 + 4 + 4) + B * T * (2 * V + 1) * 4
+        c, w_, n = both(mk, lambda a: emb(a, 1), set_bytes)
         rows.append(("tab_encoder + psi_embed_event_kernel (psi build + swap + event embedding + ScaleNorm -> fp32 + bf16)",
-                     xs_ts.numel() * 4 + V1 * T1 * E * 4 + psi_elems * 6, us))
-        us = timeit(lambda: emb(2))
-        rows.append(("time_embed_kernel (cve 1 -> 34 -> 1176, REP row appended, fp32)", xs_times.numel() * 4 + psi_elems * 4, us))
-        g1, rn = torch.ones(1, device=device), torch.rand(B * V1, device=device)
-        us = timeit(lambda: check(lib().medp_duett_swap_add_norm(ptr(xe), ptr(rn), ptr(g1), ptr(temb), T1 * V1 * E, ptr(g1), 1e-12, ptr(psi), ptr(h),
-                                                                 B, V1, T1, E, stream()), "swap_add_norm"))
-        rows.append(("swap_add_norm_kernel (event -> time view + time embedding + ScaleNorm -> fp32 + bf16)", psi_elems * (4 + 4 + 4 + 2), us))
-    return [{"kernel": n, "algorithmic_bytes": int(by), "us": round(us, 2), "GBps": round(by / us * 1e-3, 1),
-             "frac_of_hbm_peak": round(by / us * 1e-3 / PEAK_HBM_GBS, 4)} for n, by, us in rows]
+                     B * T * (2 * V + 1) * 4 + V1 * T1 * E * 4 + psi_elems * 6, c, w_, n))
+        c, w_, n = both(mk, lambda a: emb(a, 2), set_bytes)
+        rows.append(("time_embed_kernel (cve 1 -> 34 -> 1176, REP row appended, fp32)", B * T * 4 + psi_elems * 4, c, w_, n))
+        c, w_, n = both(mk, lambda a: check(lib().medp_duett_swap_add_norm(ptr(a["xe"]), ptr(a["rn"]), ptr(g1), ptr(a["temb"]), T1 * V1 * E, ptr(g1), 1e-12,
+                                                                           ptr(a["psi"]), ptr(a["h"]), B, V1, T1, E, stream()), "swap_add_norm"), set_bytes)
+        rows.append(("swap_add_norm_kernel (event -> time view + time embedding + ScaleNorm -> fp32 + bf16)", psi_elems * (4 + 4 + 4 + 2), c, w_, n))
+    return [{"kernel": nm, "algorithmic_bytes": int(by), "us": round(c, 2), "us_warm": round(w_, 2),
+             "timing": f"cold: isolated launches rotating over {n} operand sets (> 256 MiB between two uses of a buffer); us_warm: one set repeated (Infinity-Cache resident)",
+             "GBps": round(by / c * 1e-3, 1), "frac_of_hbm_peak": round(by / c * 1e-3 / PEAK_HBM_GBS, 4)} for nm, by, c, w_, n in rows]
 
 
 def main():
@@ -296,7 +319,7 @@ def main():
         # 200) is the faster arrangement — the opposite of the two-branch steps (csrc/gemm_bf16.hip; read once, at the first GEMM)
         os.environ.setdefault("MEDP_GEMM_RAGGED", "1")
     ccfg = CohortCfg(n_timesteps=T, n_vars=V, d_static=DS, image_size=img, n_labels=K, seed=1234)
-    side = args.stress or args.unfreeze_cxr or args.resident or args.eager or args.no_pipeline
+    side = args.stress or args.unfreeze_cxr or args.host_batches or args.eager or args.no_pipeline
     pipeline = not (args.no_pipeline or args.unfreeze_cxr)
 
     # ---- models, loss, optimiser -----------------------------------------------------------------------------------------------
@@ -445,26 +468,35 @@ def main():
     import warnings
     warnings.filterwarnings("ignore", message=".*lr_scheduler.step.*")
 
-    def timed(pool, steps, warmup, first=0):
+    def timed(pool, steps, warmup, first=0, per_step=None):
         for i in range(warmup):
             run_step(pool, first + i)
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if per_step is not None else None
         t0 = time.perf_counter()
+        if evs:
+            evs[0].record()
         for i in range(steps):
             run_step(pool, first + warmup + i)
+            if evs:
+                evs[i + 1].record()
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
         dt = time.perf_counter() - t0
+        if evs:
+            per_step.extend(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
         if world > 1:
             tt = torch.tensor([dt], device=device, dtype=torch.float64)
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             dt = float(tt.item())
         return dt
 
-    main_pool = dev_pool if args.resident else host_pool
+    # `value`: batches RESIDENT in HBM when the timed region starts; the PCIe-inclusive rate (pinned host batches, staged one call
+    # ahead, `feats_to_input` inside the step) is measured right after it and reported in `config` (--host-batches swaps the two)
+    main_pool = host_pool if args.host_batches else dev_pool
     if gstep is None:                                   # eager steps: HIP events bracket the GEMM launches inside the timed region
         for i in range(args.warmup):
             run_step(main_pool, i)
@@ -484,10 +516,15 @@ def main():
         if n_l.value > 0 and ms.value > 0:
             in_step = {"achieved": fl.value / (ms.value * 1e-3) / 1e12, "launches": int(n_l.value),
                        "avg_launch_us": ms.value * 1e3 / n_l.value, "flops_per_launch": fl.value / n_l.value}
-    # ---- side measurement: the same step on HBM-resident batches -----------------------------------------------------------
-    dt_res = None
-    if not args.resident and gstep is not None:
-        dt_res = timed(dev_pool, args.steps, 2, first=args.warmup + args.steps)
+    # ---- side measurements: the other batch location; per-step HIP events over max(steps, 50) steps (median) -------
+    dt_other = None
+    if gstep is not None or cfg == "probe":
+        dt_other = timed(dev_pool if args.host_batches else host_pool, args.steps, 2, first=args.warmup + args.steps)
+    per_step_ms = []
+    n_med = max(args.steps, 50)
+    timed(main_pool, n_med, 2, first=args.warmup + 2 * args.steps + 2, per_step=per_step_ms)
+    per_step_ms.sort()
+    median_ms = per_step_ms[len(per_step_ms) // 2]
     # ---- roofline leg 2: the same GEMMs alone on the GPU (HIP events around eager launches) -----------------------------------
     isolated = None
     L.medp_gemm_profile_enable(1)
@@ -507,13 +544,15 @@ def main():
 
     value = world * B * args.steps / dt
     gps = None if (args.stress or args.unfreeze_cxr) else GFLOP_PER_SAMPLE[cfg]
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    # tracked reductions of rocprofv3 runs (tools/collect_profiles.sh -> tools/make_profile_json.py), each with its source / commit / date
+    def _tracked(name):
         try:
-            traffic = json.load(open(tpath)).get("vit_gemm_hbm_bytes_per_launch")
+            return json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
-            traffic = None
+            return None
+    tj, rj = _tracked("traffic.json"), _tracked("rocprof_gemm.json")
+    traffic = tj.get("vit_gemm_hbm_bytes_per_launch") if tj else None
+    traffic_source = None if not tj else {k: tj.get(k) for k in ("source", "commit", "date", "tag")}
     names = {"teacher": "BASELINE.json configs[2]: full multimodal teacher (main_train_teacher_duett, perceiver_type=dual_patch, --freeze_duett, "
                         "frozen CXR): CXR 224x224 ViT-B/14 + DuETT T=96/F=48, bf16 MFMA / fp32 accumulate, random-init weights, synthetic "
                         "cohort seed 1234, perceiver dropout 0.2 ON",
@@ -529,7 +568,7 @@ def main():
     if args.unfreeze_cxr:
         workload = "SIDE MEASUREMENT (--unfreeze_cxr, SURVEY 8f1): " + workload + ", CXR encoder TRAINED as well, no encoder pipelining"
     if side and not (args.stress or args.unfreeze_cxr):
-        workload = "SIDE MEASUREMENT (" + ", ".join(f for f, on in (("--resident", args.resident), ("--eager", args.eager), ("--no-pipeline", args.no_pipeline)) if on) + "): " + workload
+        workload = "SIDE MEASUREMENT (" + ", ".join(f for f, on in (("--host-batches", args.host_batches), ("--eager", args.eager), ("--no-pipeline", args.no_pipeline)) if on) + "): " + workload
     execution = ("eager (engine.py from Python)" + (f" — FALLBACK, the captured step failed to build: {graph_error}" if graph_error else "")) if gstep is None else (
         ("captured HIP graph replay (graph_step.py)" + (": frozen part of batch k+1 run beside the step of batch k (one frozen forward, one "
          "trainable fwd/bwd and one update per replay; 4 distinct batches rotate)" if pipeline else ", frozen part inside its own step"))
@@ -537,11 +576,14 @@ def main():
            "graph of the next batch beside them on its own stream" if (world > 1 or force_pg) else ""))
     res = {
         "metric": "multimodal train samples/sec", "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "ms_per_step_median": round(median_ms, 3),
+        "ms_per_step_median_of": f"{n_med} steps, HIP events on the step's stream, rank 0", "higher_is_better": True,
         "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": workload, "config": cfg, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                   "batch_location": "hbm (resident)" if args.resident else "pinned host memory: H2D + feats_to_input inside the timed step",
-                   "resident_batch_samples_per_s": round(world * B * args.steps / dt_res, 2) if dt_res else None,
+                   "batch_location": ("pinned host memory: H2D + feats_to_input inside the timed step" if args.host_batches else
+                                      "HBM (resident when the timed region starts); feats_to_input inside the timed step"),
+                   ("resident_batch_samples_per_s" if args.host_batches else "pcie_inclusive_samples_per_s"):
+                       round(world * B * args.steps / dt_other, 2) if dt_other else None,
                    # graph_step's hardware-queue phase check: (pad streams, ms a step loses to the staged pixel copy, ms of that copy alone)
                    "hw_queue_phase": getattr(gstep, "phase_log", None),
                    "gflop_per_sample": gps,
@@ -556,7 +598,13 @@ def main():
             "kernel": "gemm_bf16_nt_v6_kernel<1> / gemm_bf16_nt_v7_kernel<1> (CXR-encoder block GEMMs: proj, fc2 / qkv, fc1 — one K-loop: "
                       "256x256x64 tiles, 8 waves ping-pong, 128x64 per wave; v7 = persistent over the tile list)",
             "achieved": round(in_step["achieved"], 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(in_step["achieved"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "launches": in_step["launches"],
+            "frac": round(in_step["achieved"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
+            # the same kernels' mean duration in the tracked rocprofv3 kernel trace (profiles/rocprof_gemm.json: written from ONE run that
+            # also carries that run's in-kernel clocks, so the two figures and their gap can be read side by side)
+            "frac_rocprof": None if not rj else round(in_step["flops_per_launch"] / (rj["avg_launch_us"] * 1e-6) / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "rocprof": None if not rj else {k: rj.get(k) for k in ("avg_launch_us", "launches", "same_run_in_kernel_avg_launch_us", "gap_us_per_launch",
+                                                                   "source", "commit", "date")},
+            "launches": in_step["launches"],
             "avg_launch_us": round(in_step["avg_launch_us"], 2), "algorithmic_flops_per_launch": round(in_step["flops_per_launch"], 1),
             "timing": ("in-kernel launch clocks (first workgroup in / last workgroup out, 100-MHz wall clock) of the LAST replay inside the "
                        "timed region: the GEMMs as they run in the step, beside its other branches" if gstep is not None else
@@ -567,8 +615,9 @@ def main():
         if world == 1 and not args.no_hbm_table and not args.stress:
             res["roofline"]["hbm_kernels"] = hbm_kernel_table(B, T, V, device, teacher.duett)
     if world == 1 and not args.no_cpu_baseline and not args.stress and not args.unfreeze_cxr:
-        cb = make_batch(ccfg, start=10_000, batch_size=4, mode="teacher")
-        res["cpu_baseline"] = cpu_baseline(cfg, trainable, teacher, ccfg, K, cb)
+        cb = make_batch(ccfg, start=10_000, batch_size=B, mode="teacher")            # the step's own batch ("same B")
+        cb1 = make_batch(ccfg, start=20_000, batch_size=min(4, B), mode="teacher")
+        res["cpu_baseline"] = cpu_baseline(cfg, trainable, teacher, ccfg, K, cb, cb1)
     else:
         res["cpu_baseline"] = None
     print(json.dumps(res), flush=True)

@@ -56,6 +56,22 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+def build_variant_lib(tag: str, defines: list) -> str:
+    """libmedp_hip_<tag>.so: the library with gemm_bf16_v7.hip compiled with extra -D switches (timing-only ablation builds of the
+    persistent GEMM, tools/ablate_gemm_v7.py: MEDP_V7_ABLATE_MFMA, MEDP_V7_ABLATE_LOADS).  Loaded only through MEDP_HIP_LIB."""
+    build()
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    src = os.path.join(CSRC, "gemm_bf16_v7.hip")
+    obj = os.path.join(HERE, "build", f"gemm_bf16_v7.{tag}.o")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-I", CSRC, "-I", os.path.join(ROOT, "include"),
+           "-Wno-unused-result", "-Wno-unused-value"] + [f"-D{d}" for d in defines] + ["-c", src, "-o", obj]
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    objs = [os.path.join(HERE, "build", os.path.basename(s) + ".o") for s in sources() if not s.endswith("gemm_bf16_v7.hip")] + [obj]
+    out = os.path.join(HERE, f"libmedp_hip_{tag}.so")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, check=True)
+    return out
+
+
 def build_trace_lib() -> str:
     """libmedp_hip_trace.so: the same library with gemm_bf16_v7.hip compiled -DMEDP_V7_PHASE_TRACE (in-kernel phase clocks,
     tools/trace_gemm_v7.py --phases).  A profiling aid, loaded only when MEDP_HIP_LIB points at it."""
@@ -75,6 +91,10 @@ def build_trace_lib() -> str:
 if __name__ == "__main__":
     if "--trace" in sys.argv:
         print(build_trace_lib())
+        sys.exit(0)
+    if "--ablate" in sys.argv:
+        print(build_variant_lib("nomfma", ["MEDP_V7_ABLATE_MFMA"]))
+        print(build_variant_lib("noloads", ["MEDP_V7_ABLATE_LOADS"]))
         sys.exit(0)
 
     build(force="--force" in sys.argv)

@@ -63,7 +63,11 @@ struct WaveState {
 
 // One block of up to 64 keys (rows kb*64.. of the LDS chunk) against NQW query subtiles.  nvalid = real keys in the block
 // (64 unless MASKED).
-template <int NQW, bool MASKED>
+// DEFER: deferred rescale (the running max moves only when some query of the wave sees a block maximum more than DEFER_LOG2
+// above it in exp2 units: p <= 2^DEFER_LOG2 instead of <= 1 — bf16 / fp32 are floating point, the relative precision of P, of its
+// row sum and of O is unchanged; the 16 output multiplies and the row-sum multiply of a block are skipped when nothing moved).
+constexpr float DEFER_LOG2 = 5.0f;
+template <int NQW, bool MASKED, bool DEFER = false>
 __device__ __forceinline__ void key_block(WaveState<NQW>& w, const char* sK, const char* sV, int kb, int nvalid, float c, int fr,
                                           int kq) {
     const int ktv = MASKED ? (nvalid + 15) >> 4 : 4;   // 16-key tiles holding a real key (wave-uniform)
@@ -107,10 +111,17 @@ __device__ __forceinline__ void key_block(WaveState<NQW>& w, const char* sK, con
             mx = fmaxf(fmaxf(mx, st[qs][kt][2]), st[qs][kt][3]);
         }
         mx = colmax4(mx);
-        const float m_new = fmaxf(w.m_run[qs], mx);
-        const float mc = m_new * c;
-        const float alpha = __builtin_amdgcn_exp2f(w.m_run[qs] * c - mc);
-        w.m_run[qs] = m_new;
+        bool moved = true;
+        if (DEFER) moved = __any((mx - w.m_run[qs]) * c > DEFER_LOG2) != 0;      // wave-uniform
+        float mc, alpha = 1.0f;
+        if (moved) {
+            const float m_new = fmaxf(w.m_run[qs], mx);
+            mc = m_new * c;
+            alpha = __builtin_amdgcn_exp2f(w.m_run[qs] * c - mc);
+            w.m_run[qs] = m_new;
+        } else {
+            mc = w.m_run[qs] * c;
+        }
         // Plain scalar fma / exp / add on purpose.  Written as packed pairs (v_pk_fma_f32 on the MFMA results, v_pk_add_f32
         // on the fresh v_exp_f32 results) the same arithmetic was NOT bit-stable once other kernels shared the SIMD: about
         // 1 % of launches returned a 16-query subtile off by ~1e-2 under the two-stream training step, none when the
@@ -131,9 +142,13 @@ __device__ __forceinline__ void key_block(WaveState<NQW>& w, const char* sK, con
                 ls += e0;
                 ls += e1;
             }
-        w.l_run[qs] = w.l_run[qs] * alpha + ls;
+        if (moved) {
+            w.l_run[qs] = w.l_run[qs] * alpha + ls;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) w.o[qs][dt] *= alpha;
+            for (int dt = 0; dt < 4; ++dt) w.o[qs][dt] *= alpha;
+        } else {
+            w.l_run[qs] += ls;
+        }
     }
     // ---- O^T += V^T P^T ----------------------------------------------------------------------------------------------
     const int tr_q = fr >> 2, tr_p = fr & 3;   // tr-read lane geometry: lane 4*qq+pp of a 16-lane group -> row qq, columns 4pp..4pp+3
@@ -254,6 +269,177 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dh64_kernel(const AttnParams 
     else wave_body<0>(p, sK, sV, q0, b, h, tid, wave);          // idle wave: staging share and barriers only
 }
 
+// ---- S = 257 (ViT-B/14 at 224 x 224: the class token + 256 patches): one 512-thread workgroup per (batch, head) ----------------------
+// The general kernel above cuts a (b, h) into two workgroups that EACH stage all of K / V, deals 17 query subtiles over 8 waves
+// (one wave carries 3, its workgroup waits for it: 17 / 24 of the wave-time used) and pays a masked fifth key block for ONE key.
+// Here: K / V are staged once (288-row images, 2 workgroups = 16 waves per CU); the 256 patch queries are 16 subtiles = exactly two
+// per wave; the keys are four FULL blocks of 64 (keys 0..255) and key 256 INITIALISES the online softmax (m = its score, l = 1,
+// O = its V row: p = exp2(0) = 1 exactly), so no masked block exists; the class query (row 0) is one MFMA column whose 257 keys are
+// split over the 8 waves (32 keys each, wave 0 also key 256), partial (m, l, O) combined through 2 KB of LDS by wave 7.
+constexpr int S257 = 257, CR257 = 288;
+constexpr int SCR_LD = 68;                                   // floats per wave in the class-query scratch: 64 O + m + l (+ pad)
+constexpr int LDS_257 = 2 * CR257 * 128 + 8 * SCR_LD * 4;
+
+__global__ __launch_bounds__(512, 2) void attn_fwd_dh64_s257_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;
+    char* sV = smem + CR257 * 128;
+    float* scr = (float*)(smem + 2 * CR257 * 128);
+    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = blockIdx.x, b = blockIdx.y;
+    const bf16_t* zero = (const bf16_t*)g_zero16_attn;
+    const size_t row0 = (size_t)b * S257;
+    const float c = p.scale_log2e;
+
+    // ---- stage K, V (LDS-DMA; 64 rows per pass over the 8 waves, rows 257.. are zero) ----------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        if (i == 4 && wave >= 4) break;                       // rows 256..287: waves 0-3 (wave-uniform)
+        const int row = i * 64 + (tid >> 3), ch = (tid & 7) ^ (row & 7);
+        const bool ok = row < S257;
+        const size_t grow = row0 + row;
+        glds16(ok ? p.k + grow * p.ldk + h * 64 + ch * 8 : zero, sK + (i * 512 + wave * 64) * 16);
+        glds16(ok ? p.v + grow * p.ldv + h * 64 + ch * 8 : zero, sV + (i * 512 + wave * 64) * 16);
+    }
+    // ---- Q fragments while the DMA flies: two patch subtiles per wave (queries 1 + 32 wave + 16 qs + fr), the class query in column 0
+    WaveState<2> w;
+    bf16x8 qc[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs)
+            w.qf[qs][s2] = *(const bf16x8*)(p.q + (row0 + 1 + wave * 32 + qs * 16 + fr) * p.ldq + h * 64 + s2 * 32 + kq * 8);
+        qc[s2] = *(const bf16x8*)(fr == 0 ? p.q + row0 * p.ldq + h * 64 + s2 * 32 + kq * 8 : zero);
+    }
+    MEDP_WAIT_LDS_DMA();
+    __syncthreads();
+
+    const int tr_q = fr >> 2, tr_p = fr & 3;
+    auto k_frag = [&](int krow, bf16x8& k0, bf16x8& k1) {
+        const char* base = sK + krow * 128;
+        k0 = *(const bf16x8*)(base + (((0 + kq) ^ (krow & 7)) << 4));
+        k1 = *(const bf16x8*)(base + (((4 + kq) ^ (krow & 7)) << 4));
+    };
+    // ---- class query: this wave's keys 32 wave .. 32 wave + 31 (key tiles 2 wave, 2 wave + 1); wave 0 also key 256 (tile 16) -------
+    {
+        f32x4 st[3];
+        bf16x8 k0, k1;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int kt = t < 2 ? 2 * wave + t : 16;
+            if (t == 2 && wave != 0) { st[2] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY}; continue; }
+            k_frag(kt * 16 + fr, k0, k1);
+            f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qc[0], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qc[1], a, 0, 0, 0);
+            if (t == 2) a = (f32x4){kq == 0 ? a[0] : -INFINITY, -INFINITY, -INFINITY, -INFINITY};      // only key 256 is real
+            st[t] = a;
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) mx = fmaxf(fmaxf(fmaxf(mx, st[t][0]), st[t][1]), fmaxf(st[t][2], st[t][3]));
+        mx = colmax4(mx);
+        const float mc = mx * c;
+        float ls = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __builtin_amdgcn_exp2f(fmaf(st[t][r], c, -mc));      // exp2(-inf) = 0 for the masked slots
+                st[t][r] = e;
+                ls += e;
+            }
+        ls += __shfl_xor(ls, 16, 64);
+        ls += __shfl_xor(ls, 32, 64);
+        f32x4 oc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks == 1 && wave != 0) break;
+            const f32x4 a = st[2 * ks], b2 = ks == 0 ? st[1] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            union { bf16x8 v; uint32_t u[4]; } pk;
+            pk.u[0] = pack_bf2(a[0], a[1]);
+            pk.u[1] = pack_bf2(a[2], a[3]);
+            pk.u[2] = pack_bf2(b2[0], b2[1]);
+            pk.u[3] = pack_bf2(b2[2], b2[3]);
+            const int key0 = (ks == 0 ? 2 * wave : 16) * 16 + kq * 4 + tr_q, key1 = key0 + 16;      // (tile 17 = rows 272..287: zeros)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int chunk = dt * 2 + (tr_p >> 1), off = (tr_p & 1) * 8;
+                const bf16x4 v0 = lds_tr16(sV + key0 * 128 + ((chunk ^ (key0 & 7)) << 4) + off);
+                const bf16x4 v1 = lds_tr16(sV + key1 * 128 + ((chunk ^ (key1 & 7)) << 4) + off);
+                const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                oc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pk.v, oc[dt], 0, 0, 0);
+            }
+        }
+        if (fr == 0) {                                        // column 0 = the class query: O[d = 16 dt + 4 kq + r]
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *(f32x4*)(scr + wave * SCR_LD + dt * 16 + kq * 4) = oc[dt];
+            if (kq == 0) { scr[wave * SCR_LD + 64] = mx; scr[wave * SCR_LD + 65] = ls; }
+        }
+    }
+    __syncthreads();
+    if (wave == 7) {                                          // combine the 8 partials: lane = output feature d
+        float M = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) M = fmaxf(M, scr[i * SCR_LD + 64]);
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float f = __builtin_amdgcn_exp2f((scr[i * SCR_LD + 64] - M) * c);
+            L = fmaf(scr[i * SCR_LD + 65], f, L);
+            O = fmaf(scr[i * SCR_LD + lane], f, O);
+        }
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+        const bf2_t ob = __builtin_convertvector((f32x2){O / L, 0.f}, bf2_t);
+        p.o[row0 * p.ldo + h * 64 + lane] = __builtin_bit_cast(uint32_t, ob) & 0xffffu;
+        if (p.lse && lane == 0) p.lse[((size_t)b * p.H + h) * S257] = M * c + __log2f(L);
+    }
+
+    // ---- patch queries: the online softmax starts from key 256 (tile 16, row 0 of it) ------------------------------------------------
+    {
+        bf16x8 k0, k1;
+        k_frag(256 + fr, k0, k1);
+        const int d0 = kq * 4;                                // V row 256: features 16 dt + 4 kq .. + 3 -> chunk 2 dt + (kq >> 1), half (kq & 1)
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, w.qf[qs][0], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, w.qf[qs][1], a, 0, 0, 0);
+            w.m_run[qs] = colmax4(kq == 0 ? a[0] : -INFINITY);
+            w.l_run[qs] = kq == 0 ? 1.0f : 0.0f;              // per-lane partial sums, reduced over the 4 lanes of a query at the end
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const uint2 vv = *(const uint2*)(sV + 256 * 128 + dt * 32 + d0 * 2);       // row 256: 256 & 7 == 0, no swizzle
+                w.o[qs][dt] = (f32x4){__uint_as_float(vv.x << 16), __uint_as_float(vv.x & 0xffff0000u),
+                                      __uint_as_float(vv.y << 16), __uint_as_float(vv.y & 0xffff0000u)};
+            }
+        }
+    }
+#pragma unroll 1
+    for (int kb = 0; kb < 4; ++kb) key_block<2, false, true>(w, sK, sV, kb, 64, c, fr, kq);
+
+    // ---- normalise and store: lane holds O[q][d = 16 dt + 4 kq .. + 3] ------------------------------------------------------------------
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        float l = w.l_run[qs];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const int qi = 1 + wave * 32 + qs * 16 + fr;
+        if (p.lse && kq == 0) p.lse[((size_t)b * p.H + h) * S257 + qi] = w.m_run[qs] * c + __log2f(l);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            uint2 v;
+            v.x = pack_bf2(w.o[qs][dt][0] * inv, w.o[qs][dt][1] * inv);
+            v.y = pack_bf2(w.o[qs][dt][2] * inv, w.o[qs][dt][3] * inv);
+            *(uint2*)(p.o + (row0 + qi) * p.ldo + h * 64 + dt * 16 + kq * 4) = v;
+        }
+    }
+}
+
 }  // namespace
 
 static int attn_fwd_launch(const void* q, const void* k, const void* v, void* o, float* lse, int B, int S, int H, int ldq, int ldk,
@@ -265,6 +451,16 @@ static int attn_fwd_launch(const void* q, const void* k, const void* v, void* o,
     MEDP_CHECK_ARG(scale > 0.f, "attn_fwd_dh64: scale must be positive (it is folded into the running max)");
     AttnParams p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, B, S, H, ldq, ldk, ldv, ldo,
                  scale * 1.4426950408889634f, 0, lse};
+    // S = 257 (224 x 224 images): the one-workgroup-per-(batch, head) kernel (MEDP_ATTN_S257=0: the general kernel, for A/B runs)
+    static const int s257_on = [] { const char* e = getenv("MEDP_ATTN_S257"); return e ? atoi(e) : 1; }();
+    if (S == S257 && s257_on) {
+        MEDP_ONCE_PER_DEVICE({
+            hipFuncSetAttribute((const void*)attn_fwd_dh64_s257_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_257);
+        });
+        attn_fwd_dh64_s257_kernel<<<dim3(H, B), 512, LDS_257, (hipStream_t)stream>>>(p);
+        MEDP_LAUNCH_CHECK("medp_attn_fwd_dh64(S=257)");
+        return 0;
+    }
     p.crows = min(KC, (S + 31) / 32 * 32);
     constexpr int LDS_MAX = 2 * KC * 128;
     const int LDS = 2 * p.crows * 128;

@@ -131,9 +131,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v7_kernel(const MedpGemmA
     auto set_n = [&](int nn) { n_src = nn; w_off = (unsigned)(nn + srow) * (unsigned)p.ldw + (unsigned)(schunk * 8); };
     set_m(m0);
     set_n(n0);
+#ifdef MEDP_V7_ABLATE_LOADS
+    bool ablate_on = false;          // the prologue still loads (the first tile's waits count what it issued)
+#endif
     // piece j (rows 64 j .. 64 j + 63) of half-tile `which` (0: A rows 0-127, 1: A rows 128-255, 2: W rows 0-127, 3: W rows
     // 128-255) of the K-tile at element offset k0 of the CURRENT source tile -> K buffer `b`
     auto stage_piece = [&](int k0, int b, int which, int j) {
+#ifdef MEDP_V7_ABLATE_LOADS      // timing-only build (tools/ablate_gemm_v7.py): the K-loop without its staging stream (wrong results)
+        if (ablate_on) return;
+#endif
         char* dst = smem + b * KBUF + which * HALF + wave * 1024 + j * 8192;
         const bool kin = k0 + schunk * 8 < p.K;
         const int r = (which < 2 ? m_src : n_src) + (which & 1) * 128 + j * 64 + srow;
@@ -185,6 +191,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v7_kernel(const MedpGemmA
     bool rows_live[2];
     auto mma = [&](int a, int b, const bf16x8 (*fw)[2]) {
         if (!rows_live[a]) return;
+#ifdef MEDP_V7_ABLATE_MFMA       // timing-only build: fragment reads kept alive, no matrix instructions (wrong results)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(fa[i][0]), "v"(fa[i][1])); }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { asm volatile("" ::"v"(fw[j][0]), "v"(fw[j][1])); }
+        return;
+#endif
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
@@ -234,6 +247,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v7_kernel(const MedpGemmA
     asm volatile("" : "+v"(ticket)::"memory");
     post_ticket();
     bool first = true;
+#ifdef MEDP_V7_ABLATE_LOADS
+    ablate_on = true;
+#endif
 
 #ifdef MEDP_V7_PHASE_TRACE
     unsigned pt_acc[17], pt_last = 0;

@@ -34,7 +34,7 @@ import os
 import torch
 
 from . import dp, engine
-from .streams import new_stream
+from .streams import new_stream, note_capture_origin
 from .abi import check, lib, ptr, stream
 
 
@@ -168,10 +168,12 @@ class _GraphedStep:
         self.g_fb = torch.cuda.CUDAGraph()
         if not self.split:
             with torch.cuda.graph(self.g_fb):
+                note_capture_origin(device)
                 self._advance()
                 self.out = self._whole_fwd_bwd(then=self.opt.step)
         else:
             with torch.cuda.graph(self.g_fb):
+                note_capture_origin(device)
                 self.arena.flat.zero_()
                 self._advance()
                 self.out = self._whole_fwd_bwd()
@@ -628,6 +630,7 @@ class GraphedProbeStep:
             before_capture()
         self.g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g):
+            note_capture_origin(device)
             self.out = self._whole()
         torch.cuda.synchronize(device)
         self.opt._step = int(self.opt.dev_step.item())      # capture ran opt.step() on the host without executing it

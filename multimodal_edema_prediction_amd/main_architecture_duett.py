@@ -361,6 +361,8 @@ class TeacherModel(nn.Module):
         cur = torch.cuda.current_stream()
         side = _side_stream(pixel_values.device) if (_OVERLAP and _overlap is not False) else None
         if side is not None:
+            from .streams import fork_guard
+            fork_guard("TeacherModel.forward", pixel_values.device)         # raises instead of a crash in capture_end (nested fork)
             side.wait_stream(cur)
             for t in (q0,) + tuple(duett_in):
                 if isinstance(t, torch.Tensor) and t.is_cuda:

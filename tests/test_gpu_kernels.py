@@ -177,6 +177,44 @@ def test_attn_dh64_forced_rescale():
     assert_close(got, want, 1e-2, 1e-2, "attn_dh64 rescale")
 
 
+@pytest.mark.parametrize("case", ["late_key", "key256", "cls_query", "cls_key", "ramp"])
+def test_attn_dh64_s257_rescale_paths(case):
+    """The S = 257 kernel (one workgroup per (batch, head), online softmax initialised from key 256, deferred rescale, class query
+    split over the waves): inputs that FORCE each data-dependent path (cdna guide rule 26) against fp64, every row checked, plus the
+    log-sum-exp the backward consumes.
+      late_key : a dominant key in the LAST block for some patch queries -> the rescale branch fires late
+      key256   : key 256 (the initial state) dominates -> no block ever moves the maximum (deferred path throughout)
+      cls_query: the class query has a dominant key inside ONE wave's key slice -> the 8-way partial combine must rescale
+      cls_key  : key 0 dominates every query
+      ramp     : scores grow by a few units per block: growth both below and above the defer threshold"""
+    B, S, H = 2, 257, 2
+    D = H * 64
+    qkv = bf_round(rnd(B * S, 3 * D, seed=23) * 0.5)
+    x = qkv.view(B, S, 3, H, 64)
+    if case == "late_key":
+        x[0, 250, 1, 0] = bf_round(x[0, 37, 0, 0] * 30)
+        x[1, 200, 1, 1] = bf_round(x[1, 256, 0, 1] * 30)
+    elif case == "key256":
+        x[:, 256, 1] = bf_round(x[:, 5, 0] * 12)
+    elif case == "cls_query":
+        x[0, 100, 1, 0] = bf_round(x[0, 0, 0, 0] * 25)
+        x[1, 256, 1, 1] = bf_round(x[1, 0, 0, 1] * 25)
+    elif case == "cls_key":
+        x[:, 0, 1] = bf_round(x[:, 0, 1] * 6)
+    else:
+        ramp = torch.linspace(0.2, 3.0, S).view(1, S, 1, 1)
+        x[:, :, 1] = bf_round(x[:, :, 1] * ramp)
+    qkv = x.reshape(B * S, 3 * D)
+    q, k, v = [t.reshape(B, S, H, 64).transpose(1, 2).double() for t in qkv.split(D, dim=1)]
+    sc = q @ k.transpose(-1, -2) * 0.125
+    want = (torch.softmax(sc, dim=-1) @ v).transpose(1, 2).reshape(B * S, D)
+    got, lse = Fn.attn_dh64_lse(qkv.to(DEV).bfloat16(), B, S, H, 0.125)
+    assert_close(got, want, 1e-2, 1e-2, f"attn_dh64 S=257 {case}")
+    assert_close(Fn.attn_dh64(qkv.to(DEV).bfloat16(), B, S, H, 0.125), want, 1e-2, 1e-2, f"attn_dh64 S=257 {case} (no lse)")
+    want_lse = torch.logsumexp(sc, dim=-1) * 1.4426950408889634          # log2 domain, [B, H, S]
+    assert_close(lse, want_lse, 1e-4, 2e-3, f"attn_dh64 S=257 lse {case}")
+
+
 @pytest.mark.parametrize("B,Lq,Lk,H,dh,p", [(3, 7, 256, 4, 64, 0.0), (2, 49, 49, 2, 12, 0.0), (2, 97, 97, 2, 12, 0.0),
                                             (2, 7, 7, 4, 64, 0.0), (1, 7, 1296, 4, 64, 0.0), (2, 33, 17, 2, 12, 0.0)])
 def test_attn_small_fwd_bwd(B, Lq, Lk, H, dh, p):

@@ -14,6 +14,8 @@ for cfg in teacher student probe; do
   python3 $R/bench.py --config $cfg > $O/${TAG}_bench_$cfg.json 2> $O/${TAG}_bench_$cfg.err
   tail -c 400 $O/${TAG}_bench_$cfg.json; echo
 done
+python3 $R/bench.py --stress --no-cpu-baseline > $O/${TAG}_bench_stress.json 2> $O/${TAG}_bench_stress.err      # configs[4] shapes at its per-GPU batch (B 32)
+tail -c 400 $O/${TAG}_bench_stress.json; echo
 
 for cfg in teacher student; do
   echo "[collect] kernel trace $cfg"
@@ -28,6 +30,9 @@ for cfg in teacher student; do
     python3 $R/tools/prof_summary.py $O/${TAG}_kt_$cfg 70
     if [ $cfg = teacher ]; then python3 $R/tools/prof_gemm_agreement.py $O/${TAG}_kt_$cfg 240; fi
   } > $O/${TAG}_kerneltrace_bench_$cfg.txt
+  if [ $cfg = teacher ]; then      # the trace's GEMM mean and the SAME run's in-kernel launch clocks side by side (bench.py reads it back)
+    python3 $R/tools/make_profile_json.py gemm $O/${TAG}_kt_$cfg $O/${TAG}_kt_$cfg.log $O/${TAG}_rocprof_gemm.json $TAG
+  fi
   head -12 $O/${TAG}_kerneltrace_bench_$cfg.txt
   rm -rf $O/${TAG}_kt_$cfg
 done
@@ -45,6 +50,8 @@ done
   echo "## WRITE_SIZE"; python3 $R/tools/pmc_summary.py $O/${TAG}_pmc_WRITE_SIZE WRITE_SIZE 24
 } > $O/${TAG}_pmc_fetch_write_bench_teacher.txt
 head -8 $O/${TAG}_pmc_fetch_write_bench_teacher.txt
+cp $R/profiles/traffic.json $O/${TAG}_traffic.json 2>/dev/null || true
+python3 $R/tools/make_profile_json.py traffic $O/${TAG}_pmc_FETCH_SIZE $O/${TAG}_pmc_WRITE_SIZE $O/${TAG}_traffic.json $TAG
 rm -rf $O/${TAG}_pmc_FETCH_SIZE $O/${TAG}_pmc_WRITE_SIZE
 echo "[collect] PMC SQ counters: DuETT embedding stage, CXR attention"
 SQE="SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_INSTS_LDS"

@@ -38,7 +38,7 @@ for k in range(8):
     if rag.any():
         print(f"          ragged only: K-loop {np.mean((kdone - top)[rag]):5.2f}  epilogue {np.mean((epi - kdone)[rag]):5.2f}  end wait {np.mean((landed - epi)[rag]):5.2f}")
 # per XCD end time
-last = np.array([t[b][t[b, :, 4] > 0][-1, 4] for b in range(256)])
+last = np.array([t[b][t[b, :, 4] > 0][-1, 4] if (t[b, :, 4] > 0).any() else t0 for b in range(256)])     # (fewer than 256 workgroups may run)
 print("per-XCD last end:", " ".join(f"{(last[x::8].max() - t0) / 100.0:6.1f}" for x in range(8)))
 print("per-XCD tiles   :", " ".join(f"{(t[x::8, :, 1] > 0).sum():6d}" for x in range(8)))
 
@@ -46,8 +46,8 @@ if ph.any():
     names = ["load", "bar1", "mfma", "bar2"]
     nk = D // 64
     ntile = (t[:, :, 1] > 0).sum(axis=1)                     # tiles per workgroup
-    per = ph / (ntile[:, None, None] * nk)                   # ticks per K-tile
-    full = ntile == ntile.max() if (ntile.max() != ntile.min()) else np.ones(256, bool)
+    ran = ntile > 0
+    per = ph[ran] / (ntile[ran, None, None] * nk)            # ticks per K-tile
     for grp, waves in (("group 0 (waves 0-3)", slice(0, 4)), ("group 1 (waves 4-7)", slice(4, 8))):
         m = per[:, waves, :].mean(axis=(0, 1))
         print(grp + ": ticks per K-tile  " + "  ".join(f"P{k // 4 + 1}.{names[k % 4]} {m[k]:6.1f}" for k in range(16)) + f"   sum {m.sum():7.1f}")
