@@ -98,6 +98,22 @@ def self_launch(args) -> int:
     return rc if rc != 0 else (0 if line is not None else 1)
 
 
+def shard_plan(args, rank: int, world: int, pool_index: int = 0):
+    """(per-GPU batch B, cohort indices this rank trains on in pool batch `pool_index`): SURVEY.md §8(e) — rank r takes items
+    r, r + N, ... of every global batch (accelerate's BatchSamplerShard split).  Weak scaling: --batch per GPU; --strong: the global
+    --batch is sharded, --batch / N per GPU."""
+    if args.strong:
+        if args.batch % world:
+            raise SystemExit(f"--strong: the global batch {args.batch} must divide by the number of GPUs {world}")
+        B = args.batch // world
+    else:
+        B = args.batch
+    if args.stress:
+        B = 32 if args.batch == 64 else B
+    start = pool_index * B * world + rank
+    return B, [start + i * world for i in range(B)]
+
+
 def usable_cores() -> int:
     """Cores this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU box hands a 1-GPU job a
     16-core share of a 256-thread host; running 256 torch threads on it oversubscribes ~16x)."""
@@ -278,8 +294,20 @@ def main():
         tt = torch.tensor([float(rank + 1)], dtype=torch.float64)
         if world > 1:
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        # shard arithmetic of the real run: every rank's cohort indices for the first two pool batches, gathered on rank 0
+        Bc, mine = shard_plan(args, rank, world, 0)
+        mine = mine + shard_plan(args, rank, world, 1)[1]
+        parts = [None] * world
+        if world > 1:
+            torch.distributed.all_gather_object(parts, mine)
+        else:
+            parts = [mine]
         if rank == 0:
-            print(json.dumps({"metric": "launch-check", "value": float(tt.item()), "n_gpus": world, "scaling": "strong" if args.strong else "weak"}), flush=True)
+            flat = sorted(i for p_ in parts for i in p_)
+            print(json.dumps({"metric": "launch-check", "value": float(tt.item()), "n_gpus": world, "scaling": "strong" if args.strong else "weak",
+                              "per_gpu_batch": Bc, "global_batch": Bc * world,
+                              "shards_cover_global_batches_exactly_once": flat == list(range(2 * Bc * world)),
+                              "rank0_first_items": parts[0][:3]}), flush=True)
         if torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
         return
@@ -304,15 +332,9 @@ def main():
 
     T, V, DS, K = 96, 48, 8, 7
     img = 224
-    if args.strong:
-        if args.batch % world:
-            raise SystemExit(f"--strong: the global batch {args.batch} must divide by the number of GPUs {world}")
-        B = args.batch // world
-    else:
-        B = args.batch
+    B, _ = shard_plan(args, rank, world)
     if args.stress:
         T, V, img = 256, 96, 512
-        B = 32 if args.batch == 64 else B
     cfg = args.config
     if cfg == "probe":
         # nothing runs beside the encoder here: fc1's ragged last rows as their own launch (3 full rounds of 256 workgroups instead of 4 of
@@ -350,7 +372,7 @@ def main():
     n_pool = 4
     host_pool, dev_pool = [], []
     for i in range(n_pool):
-        bt = make_batch(ccfg, start=i * B * world + rank, batch_size=B, mode="teacher", stride=world)
+        bt = make_batch(ccfg, start=shard_plan(args, rank, world, i)[1][0], batch_size=B, mode="teacher", stride=world)
         # host batches as a DataLoader(pin_memory=True) hands them over: pinned pages, per-sample tuples stacked by the collate
         hb = dict(bt, x_ts=torch.stack(tuple(bt["x_ts"])).pin_memory(), x_static=torch.stack(tuple(bt["x_static"])).pin_memory(),
                   bin_ends=torch.stack(tuple(bt["bin_ends"])).pin_memory(), pixel_values=bt["pixel_values"].pin_memory(),
@@ -589,6 +611,8 @@ def main():
                    "gflop_per_sample": gps,
                    "step_mfma_fraction_of_peak": None if gps is None else round(value * gps / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
                    "last_loss": round(last_loss, 5), "execution": execution,
+                   # N > 1 (or MEDP_FORCE_PG=1): per-step HIP-event times of the gradient all-reduce and the optimiser update
+                   "split_step_ms": gstep.split_timings() if (gstep is not None and hasattr(gstep, "split_timings")) else None,
                    "gradient_exchange_bytes": (gstep.arena.bytes_per_step if (gstep is not None and gstep.arena is not None) else
                                                (reducer.bytes_per_step if reducer is not None else 0))},
     }

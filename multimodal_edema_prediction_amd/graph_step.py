@@ -292,13 +292,40 @@ class _GraphedStep:
         if not self.split:
             self.opt.note_external_step()
             return self.out
+        # split arrangement: HIP events on the step's stream around the collective and the update, every step (a ring of the last
+        # 64 steps; read by `split_timings()` — bench.py reports them in the N > 1 line so that the first multi-GPU run shows what
+        # the exchange costs per step).  The process group makes this stream wait for the collective, so ev1 fires when it is done.
+        ring = self._split_events()
+        ring[0].record()
         self._allreduce()                            # RCCL on its own stream, ordered after g_fb by the process group
+        ring[1].record()
         if self.g_opt is not None:
             self.g_opt.replay()
             self.opt.note_external_step()
         else:
             self.opt.relaunch()
+        ring[2].record()
         return self.out
+
+    def _split_events(self):
+        if not hasattr(self, "_sev"):
+            self._sev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(64)]
+            self._sev_n = 0
+        ev = self._sev[self._sev_n % 64]
+        self._sev_n += 1
+        return ev
+
+    def split_timings(self):
+        """Mean milliseconds per step of the gradient all-reduce and of the optimiser update over the last (up to 64) split-mode
+        steps, None when the step is not split.  Synchronises the device."""
+        n = min(getattr(self, "_sev_n", 0), 64)
+        if n == 0:
+            return None
+        torch.cuda.synchronize(self.device)
+        ar = sum(e[0].elapsed_time(e[1]) for e in self._sev[:n]) / n
+        up = sum(e[1].elapsed_time(e[2]) for e in self._sev[:n]) / n
+        return {"allreduce_ms": round(ar, 4), "optimizer_ms": round(up, 4), "steps": n,
+                "collective": "one mean all-reduce of the flat fp32 gradient arena between the forward/backward graph and the optimiser launches"}
 
 
 class GraphedTeacherStep(_GraphedStep):

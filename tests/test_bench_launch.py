@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.timeout(180)
-@pytest.mark.parametrize("n,extra", [(2, []), (3, ["--strong"]), (1, [])])
+@pytest.mark.parametrize("n,extra", [(2, []), (2, ["--strong"]), (3, ["--strong", "--batch", "63"]), (1, [])])
 def test_bench_self_launches_one_rank_per_gpu(n, extra):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--launch-check"] + extra,
@@ -23,3 +23,8 @@ def test_bench_self_launches_one_rank_per_gpu(n, extra):
     out = json.loads(lines[0])
     assert out["n_gpus"] == n and out["value"] == float(n)          # MAX over ranks of (rank + 1): every rank took part
     assert out["scaling"] == ("strong" if extra else "weak")
+    # SURVEY.md §8(e) shard arithmetic, as the real run computes it: weak = --batch per GPU, --strong = --batch / N per GPU; rank r takes
+    # items r, r + N, ... of every global batch, and the ranks together cover each global batch exactly once
+    batch = int(extra[extra.index("--batch") + 1]) if "--batch" in extra else 64
+    assert out["per_gpu_batch"] == (batch // n if "--strong" in extra else batch) and out["global_batch"] == out["per_gpu_batch"] * n
+    assert out["shards_cover_global_batches_exactly_once"] is True and out["rank0_first_items"] == [0, n, 2 * n]
