@@ -164,6 +164,11 @@ typedef struct {
     const float* fc1_b;
     const void* fc2_w;            /* bf16 [hidden, mlp] */
     const float *fc2_b, *ls2;
+    /* LayerNorm folded into the qkv / fc1 GEMMs (all six non-NULL, or the LayerNorm launches stay): LN(x) W^T + b =
+     * rstd (x (W g)^T) - rstd mean colsum(W g) + (b + W beta).  *_wg = bf16(W * ln_w) [rows as *_w], *_cs = fp32 row sums of the bf16
+     * *_wg [3*hidden / mlp], *_b2 = b + W ln_b (fp32).  Used for batches whose block GEMMs take the 256-tile kernels. */
+    const void *qkv_wg, *fc1_wg;
+    const float *qkv_cs, *qkv_b2, *fc1_cs, *fc1_b2;
 } MedpVitLayer;
 
 typedef struct {

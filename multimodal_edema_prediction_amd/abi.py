@@ -19,7 +19,8 @@ P, I, F, U, LL, SZ = c_void_p, c_int, c_float, c_uint, c_longlong, c_size_t
 
 class MedpVitLayer(ctypes.Structure):
     _fields_ = [(n, P) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1", "ln2_w", "ln2_b",
-                                 "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2")]
+                                 "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2",
+                                 "qkv_wg", "fc1_wg", "qkv_cs", "qkv_b2", "fc1_cs", "fc1_b2")]      # LayerNorm fold (include/medp_hip.h)
 
 
 class MedpVitWeights(ctypes.Structure):

@@ -280,40 +280,50 @@ constexpr int S257 = 257, CR257 = 288;
 constexpr int SCR_LD = 68;                                   // floats per wave in the class-query scratch: 64 O + m + l (+ pad)
 constexpr int LDS_257 = 2 * CR257 * 128 + 8 * SCR_LD * 4;
 
-__global__ __launch_bounds__(512, 2) void attn_fwd_dh64_s257_kernel(const AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sK = smem;
-    char* sV = smem + CR257 * 128;
-    float* scr = (float*)(smem + 2 * CR257 * 128);
-    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, kq = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = blockIdx.x, b = blockIdx.y;
+// One work unit of the S = 257 kernel: the patch-query subtiles t0 .. t0 + NQW - 1 of (b, h) for this wave (NQW = 2: a whole (b, h) per
+// workgroup, wave w takes subtiles 2w, 2w+1; NQW = 1: HALF a (b, h), wave w takes subtile 8 half + w) and, when `do_cls`, the class query.
+template <int NQW>
+__device__ __forceinline__ void s257_unit(const AttnParams& p, char* sK, char* sV, float* scr, int b, int h, int t0, bool do_cls, int tid,
+                                          int wave) {
+    const int lane = tid & 63, fr = lane & 15, kq = lane >> 4;
     const bf16_t* zero = (const bf16_t*)g_zero16_attn;
     const size_t row0 = (size_t)b * S257;
     const float c = p.scale_log2e;
 
-    // ---- stage K, V (LDS-DMA; 64 rows per pass over the 8 waves, rows 257.. are zero) ----------------------------------------------
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        if (i == 4 && wave >= 4) break;                       // rows 256..287: waves 0-3 (wave-uniform)
-        const int row = i * 64 + (tid >> 3), ch = (tid & 7) ^ (row & 7);
+    // ---- loads, in the order they are needed, every wave the SAME number of vector-memory operations (vmcnt retires in order):
+    //   2 LDS-DMA pieces: K / V rows 256..287 (key 256 initialises the online softmax; waves 4-7 rewrite the pieces of waves 0-3 with the
+    //                     same bytes, so that the counts below hold for every wave)
+    //   2 NQW + 2 register loads: the Q fragments (inline asm: beside LDS-DMA hipcc would retire the WHOLE queue at the first use of an
+    //                     ordinary load's result — cdna guide §5 trap (b) — and the key blocks below could not start before the last row landed)
+    //   8 LDS-DMA pieces: K / V rows 64 i .. 64 i + 63 = key block i, i = 0..3
+    // Key block i waits for "all but the 2 (3 - i) youngest" and a raw barrier (every wave has then passed ITS wait): the first block runs
+    // while three quarters of K / V are still in flight — the launch reads 76 MB and writes 25 MB, HBM time is what bounds it.
+    auto stage_pass = [&](int i, int wsrc) {
+        const int row = i * 64 + (wsrc * 8 + (lane >> 3)), ch = (lane & 7) ^ (row & 7);
         const bool ok = row < S257;
         const size_t grow = row0 + row;
-        glds16(ok ? p.k + grow * p.ldk + h * 64 + ch * 8 : zero, sK + (i * 512 + wave * 64) * 16);
-        glds16(ok ? p.v + grow * p.ldv + h * 64 + ch * 8 : zero, sV + (i * 512 + wave * 64) * 16);
-    }
-    // ---- Q fragments while the DMA flies: two patch subtiles per wave (queries 1 + 32 wave + 16 qs + fr), the class query in column 0
-    WaveState<2> w;
+        glds16(ok ? p.k + grow * p.ldk + h * 64 + ch * 8 : zero, sK + (i * 512 + wsrc * 64) * 16);
+        glds16(ok ? p.v + grow * p.ldv + h * 64 + ch * 8 : zero, sV + (i * 512 + wsrc * 64) * 16);
+    };
+    stage_pass(4, wave & 3);
+    WaveState<NQW> w;
     bf16x8 qc[2];
+    auto ld16 = [&](bf16x8& dst, const bf16_t* src) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory"); };
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
-        for (int qs = 0; qs < 2; ++qs)
-            w.qf[qs][s2] = *(const bf16x8*)(p.q + (row0 + 1 + wave * 32 + qs * 16 + fr) * p.ldq + h * 64 + s2 * 32 + kq * 8);
-        qc[s2] = *(const bf16x8*)(fr == 0 ? p.q + row0 * p.ldq + h * 64 + s2 * 32 + kq * 8 : zero);
+        for (int qs = 0; qs < NQW; ++qs) ld16(w.qf[qs][s2], p.q + (row0 + 1 + (t0 + qs) * 16 + fr) * p.ldq + h * 64 + s2 * 32 + kq * 8);
+        ld16(qc[s2], (do_cls && fr == 0) ? p.q + row0 * p.ldq + h * 64 + s2 * 32 + kq * 8 : zero);
     }
-    MEDP_WAIT_LDS_DMA();
-    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stage_pass(i, wave);
+    // rows 256..287 and the Q fragments have landed (8 pieces may still fly); the asm names the fragments so that no use moves above it
+    if constexpr (NQW == 2)
+        asm volatile("s_waitcnt vmcnt(8)" : "+v"(w.qf[0][0]), "+v"(w.qf[0][1]), "+v"(w.qf[1][0]), "+v"(w.qf[1][1]), "+v"(qc[0]), "+v"(qc[1])::"memory");
+    else
+        asm volatile("s_waitcnt vmcnt(8)" : "+v"(w.qf[0][0]), "+v"(w.qf[0][1]), "+v"(qc[0]), "+v"(qc[1])::"memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
 
     const int tr_q = fr >> 2, tr_p = fr & 3;
     auto k_frag = [&](int krow, bf16x8& k0, bf16x8& k1) {
@@ -321,8 +331,59 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_dh64_s257_kernel(const AttnPa
         k0 = *(const bf16x8*)(base + (((0 + kq) ^ (krow & 7)) << 4));
         k1 = *(const bf16x8*)(base + (((4 + kq) ^ (krow & 7)) << 4));
     };
-    // ---- class query: this wave's keys 32 wave .. 32 wave + 31 (key tiles 2 wave, 2 wave + 1); wave 0 also key 256 (tile 16) -------
+    // ---- patch queries: the online softmax starts from key 256 (tile 16, row 0 of it) ------------------------------------------------
     {
+        bf16x8 k0, k1;
+        k_frag(256 + fr, k0, k1);
+        const int d0 = kq * 4;                                // V row 256: features 16 dt + 4 kq .. + 3 -> chunk 2 dt + (kq >> 1), half (kq & 1)
+#pragma unroll
+        for (int qs = 0; qs < NQW; ++qs) {
+            f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, w.qf[qs][0], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, w.qf[qs][1], a, 0, 0, 0);
+            w.m_run[qs] = colmax4(kq == 0 ? a[0] : -INFINITY);
+            w.l_run[qs] = kq == 0 ? 1.0f : 0.0f;              // per-lane partial sums, reduced over the 4 lanes of a query at the end
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                // (read as a bf16 vector like every other read of the staged images: a `uint2`-typed read made hipcc put s_waitcnt vmcnt(0)
+                //  in front of it — it may alias the LDS-DMA in flight — and the key blocks waited for the whole of K / V again)
+                const bf16x4 vq = *(const bf16x4*)(sV + 256 * 128 + dt * 32 + d0 * 2);       // row 256: 256 & 7 == 0, no swizzle
+                const uint2 vv = __builtin_bit_cast(uint2, vq);
+                w.o[qs][dt] = (f32x4){__uint_as_float(vv.x << 16), __uint_as_float(vv.x & 0xffff0000u),
+                                      __uint_as_float(vv.y << 16), __uint_as_float(vv.y & 0xffff0000u)};
+            }
+        }
+    }
+#pragma unroll 1
+    for (int kb = 0; kb < 4; ++kb) {                          // (not unrolled: four copies of the block body cost 40 VGPRs and a wave per SIMD)
+        if (kb == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (kb == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (kb == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                         // every wave's pieces of rows 64 kb .. 64 kb + 63 have landed
+        __builtin_amdgcn_sched_barrier(0);
+        key_block<NQW, false, true>(w, sK, sV, kb, 64, c, fr, kq);
+    }
+
+    // ---- normalise and store: lane holds O[q][d = 16 dt + 4 kq .. + 3] ------------------------------------------------------------------
+#pragma unroll
+    for (int qs = 0; qs < NQW; ++qs) {
+        float l = w.l_run[qs];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const int qi = 1 + (t0 + qs) * 16 + fr;
+        if (p.lse && kq == 0) p.lse[((size_t)b * p.H + h) * S257 + qi] = w.m_run[qs] * c + __log2f(l);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            uint2 v;
+            v.x = pack_bf2(w.o[qs][dt][0] * inv, w.o[qs][dt][1] * inv);
+            v.y = pack_bf2(w.o[qs][dt][2] * inv, w.o[qs][dt][3] * inv);
+            *(uint2*)(p.o + (row0 + qi) * p.ldo + h * 64 + dt * 16 + kq * 4) = v;
+        }
+    }
+    // ---- class query (all of K / V has landed by now): this wave's keys 32 wave .. 32 wave + 31 (key tiles 2 wave, 2 wave + 1); wave 0 also key 256 (tile 16) -------
+    if (do_cls) {                                             // (workgroup-uniform)
         f32x4 st[3];
         bf16x8 k0, k1;
 #pragma unroll
@@ -379,68 +440,48 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_dh64_s257_kernel(const AttnPa
             for (int dt = 0; dt < 4; ++dt) *(f32x4*)(scr + wave * SCR_LD + dt * 16 + kq * 4) = oc[dt];
             if (kq == 0) { scr[wave * SCR_LD + 64] = mx; scr[wave * SCR_LD + 65] = ls; }
         }
-    }
-    __syncthreads();
-    if (wave == 7) {                                          // combine the 8 partials: lane = output feature d
-        float M = -INFINITY;
+        __syncthreads();
+        if (wave == 7) {                                      // combine the 8 partials: lane = output feature d
+            float M = -INFINITY;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) M = fmaxf(M, scr[i * SCR_LD + 64]);
-        float L = 0.f, O = 0.f;
+            for (int i = 0; i < 8; ++i) M = fmaxf(M, scr[i * SCR_LD + 64]);
+            float L = 0.f, O = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float f = __builtin_amdgcn_exp2f((scr[i * SCR_LD + 64] - M) * c);
-            L = fmaf(scr[i * SCR_LD + 65], f, L);
-            O = fmaf(scr[i * SCR_LD + lane], f, O);
-        }
-        typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
-        const bf2_t ob = __builtin_convertvector((f32x2){O / L, 0.f}, bf2_t);
-        p.o[row0 * p.ldo + h * 64 + lane] = __builtin_bit_cast(uint32_t, ob) & 0xffffu;
-        if (p.lse && lane == 0) p.lse[((size_t)b * p.H + h) * S257] = M * c + __log2f(L);
-    }
-
-    // ---- patch queries: the online softmax starts from key 256 (tile 16, row 0 of it) ------------------------------------------------
-    {
-        bf16x8 k0, k1;
-        k_frag(256 + fr, k0, k1);
-        const int d0 = kq * 4;                                // V row 256: features 16 dt + 4 kq .. + 3 -> chunk 2 dt + (kq >> 1), half (kq & 1)
-#pragma unroll
-        for (int qs = 0; qs < 2; ++qs) {
-            f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, w.qf[qs][0], a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, w.qf[qs][1], a, 0, 0, 0);
-            w.m_run[qs] = colmax4(kq == 0 ? a[0] : -INFINITY);
-            w.l_run[qs] = kq == 0 ? 1.0f : 0.0f;              // per-lane partial sums, reduced over the 4 lanes of a query at the end
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const uint2 vv = *(const uint2*)(sV + 256 * 128 + dt * 32 + d0 * 2);       // row 256: 256 & 7 == 0, no swizzle
-                w.o[qs][dt] = (f32x4){__uint_as_float(vv.x << 16), __uint_as_float(vv.x & 0xffff0000u),
-                                      __uint_as_float(vv.y << 16), __uint_as_float(vv.y & 0xffff0000u)};
+            for (int i = 0; i < 8; ++i) {
+                const float f = __builtin_amdgcn_exp2f((scr[i * SCR_LD + 64] - M) * c);
+                L = fmaf(scr[i * SCR_LD + 65], f, L);
+                O = fmaf(scr[i * SCR_LD + lane], f, O);
             }
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+            const bf2_t ob = __builtin_convertvector((f32x2){O / L, 0.f}, bf2_t);
+            p.o[row0 * p.ldo + h * 64 + lane] = __builtin_bit_cast(uint32_t, ob) & 0xffffu;
+            if (p.lse && lane == 0) p.lse[((size_t)b * p.H + h) * S257] = M * c + __log2f(L);
         }
     }
-#pragma unroll 1
-    for (int kb = 0; kb < 4; ++kb) key_block<2, false, true>(w, sK, sV, kb, 64, c, fr, kq);
 
-    // ---- normalise and store: lane holds O[q][d = 16 dt + 4 kq .. + 3] ------------------------------------------------------------------
-#pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
-        float l = w.l_run[qs];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        const float inv = 1.0f / l;
-        const int qi = 1 + wave * 32 + qs * 16 + fr;
-        if (p.lse && kq == 0) p.lse[((size_t)b * p.H + h) * S257 + qi] = w.m_run[qs] * c + __log2f(l);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            uint2 v;
-            v.x = pack_bf2(w.o[qs][dt][0] * inv, w.o[qs][dt][1] * inv);
-            v.y = pack_bf2(w.o[qs][dt][2] * inv, w.o[qs][dt][3] * inv);
-            *(uint2*)(p.o + (row0 + qi) * p.ldo + h * 64 + dt * 16 + kq * 4) = v;
-        }
-    }
+}
+
+// NQW = 2: workgroup i does the whole (b, h) = item0 + i (two subtiles per wave).  NQW = 1: workgroup i does HALF of (b, h) = item0 + i / 2
+// (8 query subtiles, one per wave; the even half also the class query), staging K / V for it.  The launcher runs the (b, h) that fill
+// whole rounds of the 2-per-CU resident slots as <2> and a remainder of at most half a round as <1> halves: B H = 768 on 512 slots is one
+// round of whole units + one round of half units (1.55 unit-times) instead of a second round that leaves every second slot idle (2).
+template <int NQW>
+__global__ __launch_bounds__(512, 2) void attn_fwd_dh64_s257_kernel(const AttnParams p, const int item0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;
+    char* sV = smem + CR257 * 128;
+    float* scr = (float*)(smem + 2 * CR257 * 128);
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int item = item0 + (NQW == 2 ? (int)blockIdx.x : (int)(blockIdx.x >> 1));
+    const int half = NQW == 2 ? 0 : (int)(blockIdx.x & 1);
+    const int b = item / p.H, h = item - b * p.H;
+    s257_unit<NQW>(p, sK, sV, scr, b, h, NQW == 2 ? 2 * wave : 8 * half + wave, half == 0, tid, wave);
 }
 
 }  // namespace
+
+static int g_s257_slots_override = 0;       // medp_dbg_attn_s257_slots (tests): pretend the device has this many resident slots
 
 static int attn_fwd_launch(const void* q, const void* k, const void* v, void* o, float* lse, int B, int S, int H, int ldq, int ldk,
                            int ldv, int ldo, float scale, void* stream) {
@@ -455,9 +496,20 @@ static int attn_fwd_launch(const void* q, const void* k, const void* v, void* o,
     static const int s257_on = [] { const char* e = getenv("MEDP_ATTN_S257"); return e ? atoi(e) : 1; }();
     if (S == S257 && s257_on) {
         MEDP_ONCE_PER_DEVICE({
-            hipFuncSetAttribute((const void*)attn_fwd_dh64_s257_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_257);
+            hipFuncSetAttribute((const void*)attn_fwd_dh64_s257_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_257);
+            hipFuncSetAttribute((const void*)attn_fwd_dh64_s257_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_257);
         });
-        attn_fwd_dh64_s257_kernel<<<dim3(H, B), 512, LDS_257, (hipStream_t)stream>>>(p);
+        // resident slots: 2 workgroups per CU (LDS).  Whole rounds of (b, h) as <2>; a remainder of at most half a round as <1> halves
+        // (MEDP_ATTN_S257_BALANCE=1 or medp_dbg_attn_s257_slots: the half-unit arrangement, kept for A/B runs and its test)
+        static const int dev_slots = [] { int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); return 2 * cus; }();
+        const int slots = g_s257_slots_override > 0 ? g_s257_slots_override : dev_slots;
+        // Measured (B 64, H 12: 768 (b, h) on 512 slots): whole units only 32.2 us, whole + half units 37.8 us — a (b, h)'s cost is its 99 KB of
+        // loads, not its 16 subtiles of arithmetic, and a half unit loads all of K / V for half the queries.  Default: whole units.
+        static const int bal = [] { const char* e = getenv("MEDP_ATTN_S257_BALANCE"); return e ? atoi(e) : 0; }();
+        const int n = B * H, rem = n % slots;
+        const int n_half = (bal && n > slots && rem > 0 && 2 * rem <= slots) ? rem : 0, n_whole = n - n_half;
+        attn_fwd_dh64_s257_kernel<2><<<n_whole, 512, LDS_257, (hipStream_t)stream>>>(p, 0);
+        if (n_half) attn_fwd_dh64_s257_kernel<1><<<2 * n_half, 512, LDS_257, (hipStream_t)stream>>>(p, n_whole);
         MEDP_LAUNCH_CHECK("medp_attn_fwd_dh64(S=257)");
         return 0;
     }
@@ -484,4 +536,12 @@ extern "C" int medp_attn_fwd_dh64_lse(const void* q, const void* k, const void* 
                                       int ldq, int ldk, int ldv, int ldo, float scale, void* stream) {
     MEDP_CHECK_ARG(lse, "attn_fwd_dh64_lse: null lse");
     return attn_fwd_launch(q, k, v, o, lse, B, S, H, ldq, ldk, ldv, ldo, scale, stream);
+}
+
+// Debug hook (NOT part of the C ABI in include/medp_hip.h; tests/test_gpu_kernels.py): resident-slot count the S = 257 launcher plans
+// with (0 = the device's own 2 x CUs), so that the half-unit kernel can be exercised at small B x H.  Returns the previous value.
+extern "C" int medp_dbg_attn_s257_slots(int slots) {
+    const int prev = g_s257_slots_override;
+    g_s257_slots_override = slots > 0 ? slots : 0;
+    return prev;
 }

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const float* __restrict
         float h = 0.f;
         if (row < rows) {
             const int b = row / (T + 1), t = row - b * (T + 1);
-            if (t < T) h = tanhf(w0[j] * times[(size_t)b * T + t] + b0[j]) * s[j] + sh[j];
+            if (t < T) h = fmaf(tanhf(fmaf(w0[j], times[(size_t)b * T + t], b0[j])), s[j], sh[j]);      // (explicit fmaf: the same in time_embed_mfma_kernel)
         }
         hid[j * TE_ROWS + rr] = h;             // [Hd][TE_ROWS]: the 16 rows of one hidden unit are one 64-B broadcast read
     }
@@ -144,14 +144,15 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const float* __restrict
 #pragma unroll
             for (int q = 0; q < TE_ROWS / 4; ++q) {
                 const float4 h4 = hj[q];
-                acc[4 * q] += w[u] * h4.x; acc[4 * q + 1] += w[u] * h4.y; acc[4 * q + 2] += w[u] * h4.z; acc[4 * q + 3] += w[u] * h4.w;
+                acc[4 * q] = fmaf(w[u], h4.x, acc[4 * q]); acc[4 * q + 1] = fmaf(w[u], h4.y, acc[4 * q + 1]);
+                acc[4 * q + 2] = fmaf(w[u], h4.z, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(w[u], h4.w, acc[4 * q + 3]);
             }
         }
     }
     for (; j < Hd; ++j) {
         const float w = w3[(size_t)j * tt + c];
 #pragma unroll
-        for (int rr = 0; rr < TE_ROWS; ++rr) acc[rr] += w * hid[j * TE_ROWS + rr];
+        for (int rr = 0; rr < TE_ROWS; ++rr) acc[rr] = fmaf(w, hid[j * TE_ROWS + rr], acc[rr]);
     }
     const float repc = rep[c];
 #pragma unroll
@@ -159,6 +160,105 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const float* __restrict
         const int row = r0 + rr;
         if (row < rows) out[(size_t)row * tt + c] = (row % (T + 1) == T) ? repc : acc[rr];     // REP row appended
     }
+}
+
+// ---- time embedding on the matrix cores, in exact fp32 --------------------------------------------------------------------------------
+// out[row][c] = b3[c] + sum_j w3t[j][c] * hid[row][j] is a [B(T+1) x Hd] x [Hd x tt] product (6208 x 34 x 1176 at cfg3): 0.5 GFLOP behind a
+// 29-MB store.  v_mfma_f32_16x16x4_f32 takes fp32 operands and its result is bit for bit the k-ordered fmaf chain the VALU kernel above
+// computes (C-in = the bias, products added in ascending j; the rows of k past Hd are zeros: fma(0, 0, acc) = acc), so the fp32 kernel
+// mode needs no second form.  A wave owns 16 rows: each lane computes 9 of their 16 x 36 hidden activations (the A fragments, kept in
+// registers for the whole launch) and walks its share of the 16-column tiles; the B fragments come straight from the L2-resident weight.
+constexpr int TEM_KS = 9;                                    // k-steps of 4: hidden widths up to 36
+constexpr int TEM_CW = 208;                                  // columns per workgroup (13 tiles of 16); 208 floats = 6.5 x 32 banks: the two
+                                                             // 16-lane k-groups of a 32-lane half read disjoint bank sets (conflict-free ds_read_b32)
+__global__ __launch_bounds__(256) void time_embed_mfma_kernel(const float* __restrict__ times, const float* __restrict__ w0,
+                                                              const float* __restrict__ b0, const float* __restrict__ s,
+                                                              const float* __restrict__ sh, const float* __restrict__ w3t,
+                                                              const float* __restrict__ b3, const float* __restrict__ rep,
+                                                              float* __restrict__ out, int B, int T, int Hd, int tt) {
+    // the workgroup's slice of the second Linear, [4 TEM_KS][TEM_CW] + bias + REP rows, staged once (coalesced) and read back as B
+    // fragments by all four waves for every column tile: the first form loaded them from L2 tile by tile — 13 dependent ~1-us round
+    // trips per wave, 18.7 us for a launch whose matrix work is 3.5 us
+    __shared__ __attribute__((aligned(16))) float sw[(4 * TEM_KS + 2) * TEM_CW];
+    const int lane = threadIdx.x & 63, rr = lane & 15, kk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rows = B * (T + 1);
+    const int c0 = blockIdx.y * TEM_CW, ncol = min(TEM_CW, tt - c0);
+    {   // 38 rows of 52 float4 (the tail rows: zeros, bias, REP); every thread's 8 loads are independent and issued together — one load
+        // per loop iteration made the staging a chain of 31 L2 round trips (23 us for the launch)
+        constexpr int C4 = TEM_CW / 4, N4 = (4 * TEM_KS + 2) * C4;
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i4 = threadIdx.x + 256 * u, j = i4 / C4, cc = (i4 - j * C4) * 4;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i4 < N4 && cc < ncol) {                    // (tt and the chunk width are multiples of 4: a float4 is all in or all out)
+                const float* src = j < Hd ? w3t + (size_t)j * tt : (j == 4 * TEM_KS ? b3 : (j == 4 * TEM_KS + 1 ? rep : nullptr));
+                if (src) v[u] = *(const float4*)(src + c0 + cc);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i4 = threadIdx.x + 256 * u;
+            if (i4 < N4) *(float4*)(sw + 4 * i4) = v[u];
+        }
+    }
+    const int r0 = (blockIdx.x * 4 + wave) * 16;
+    float a[TEM_KS];
+    {
+        const int row = r0 + rr;
+        const int b = row / (T + 1), t = row - b * (T + 1);
+        const bool live = row < rows && t < T;
+        const float tv = live ? times[(size_t)b * T + t] : 0.f;
+#pragma unroll
+        for (int ks = 0; ks < TEM_KS; ++ks) {
+            const int j = 4 * ks + kk;
+            a[ks] = (live && j < Hd) ? fmaf(tanhf(fmaf(w0[j], tv, b0[j])), s[j], sh[j]) : 0.f;
+        }
+    }
+    __syncthreads();
+    if (r0 >= rows) return;
+    bool is_rep[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) is_rep[r] = (r0 + kk * 4 + r) % (T + 1) == T;
+    const int ntile = (ncol + 15) >> 4;
+    for (int ct = 0; ct < ntile; ++ct) {
+        const int cc = ct * 16 + rr;
+        const float bias = sw[4 * TEM_KS * TEM_CW + cc], repc = sw[(4 * TEM_KS + 1) * TEM_CW + cc];
+        f32x4 acc = (f32x4){bias, bias, bias, bias};
+#pragma unroll
+        for (int ks = 0; ks < TEM_KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], sw[(4 * ks + kk) * TEM_CW + cc], acc, 0, 0, 0);
+        if (cc < ncol) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = r0 + kk * 4 + r;
+                if (row < rows) out[(size_t)row * tt + c0 + cc] = is_rep[r] ? repc : acc[r];          // REP row appended
+            }
+        }
+    }
+}
+
+// MEDP_EMBED_MFMA=0 (or medp_dbg_embed_mfma(0), tests): the VALU forms of the two embedding kernels, for A/B runs and bit comparisons
+int g_embed_mfma = -1;
+static int embed_mfma_on() {
+    if (g_embed_mfma < 0) { const char* e = getenv("MEDP_EMBED_MFMA"); g_embed_mfma = e ? (atoi(e) != 0) : 1; }
+    return g_embed_mfma;
+}
+
+static int launch_time_embed(const MedpDuettWeights* w, const float* xs_times, float* temb, int B, int T, hipStream_t s) {
+    const int T1 = T + 1, tt = w->d_embedding * (w->n_vars + 1);
+    const int mfma_on = embed_mfma_on();
+    if (mfma_on && w->d_hidden_time <= 4 * TEM_KS) {
+        time_embed_mfma_kernel<<<dim3((B * T1 + 63) / 64, (tt + TEM_CW - 1) / TEM_CW), 256, 0, s>>>(
+            xs_times, (const float*)w->time_w0, (const float*)w->time_b0, (const float*)w->time_bn_scale, (const float*)w->time_bn_shift,
+            (const float*)w->time_w3t, (const float*)w->time_b3, (const float*)w->rep_embedding, temb, B, T, w->d_hidden_time, tt);
+    } else {
+        time_embed_kernel<<<dim3((B * T1 + TE_ROWS - 1) / TE_ROWS, (tt + 255) / 256), 256, TE_ROWS * w->d_hidden_time * sizeof(float), s>>>(
+            xs_times, (const float*)w->time_w0, (const float*)w->time_b0, (const float*)w->time_bn_scale, (const float*)w->time_bn_shift,
+            (const float*)w->time_w3t, (const float*)w->time_b3, (const float*)w->rep_embedding, temb, B, T, w->d_hidden_time, tt);
+    }
+    MEDP_LAUNCH_CHECK("duett time_embed");
+    return 0;
 }
 
 // ---- axis swaps (K7): cells of E floats move between [B, A1, A2, E] and [B, A2, A1, E] ------------------------------------
@@ -206,7 +306,7 @@ __global__ __launch_bounds__(128) void psi_embed_event_kernel(const float* __res
                                                               const float* __restrict__ special,
                                                               const float* __restrict__ event_emb, const float* __restrict__ g_norm,
                                                               float norm_eps, float* __restrict__ xe, bf16_t* __restrict__ h,
-                                                              float* __restrict__ psi0_out, int B, int T, int V) {
+                                                              float* __restrict__ psi0_out, int B, int T, int V, int use_mfma) {
     // A workgroup = one variable v x PE_NB consecutive batch elements (PE_NB cells per lane, one per batch element); the
     // variable's MLP (7.5 KB) is staged in LDS once per workgroup and read back by broadcast 16-B reads.  What bounds it: every
     // lane needs the same 29 floats per hidden unit, and a wave-wide LDS read returns 1 KB through the CU's 128-B/clk LDS
@@ -250,7 +350,8 @@ __global__ __launch_bounds__(128) void psi_embed_event_kernel(const float* __res
         }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < T1; t += 128) {
+    // (whole waves enter: the matrix-core path below needs all 64 lanes; t >= T1 is "no cell" and is never stored)
+    for (int t = threadIdx.x; t < ((T1 + 63) & ~63); t += 128) {
         float out[PE_NB][E];
         float val[PE_NB], nob[PE_NB];
         const float* src[PE_NB];
@@ -271,7 +372,7 @@ __global__ __launch_bounds__(128) void psi_embed_event_kernel(const float* __res
         for (int bb = 0; bb < PE_NB; ++bb) {
             src[bb] = nullptr;
             nob[bb] = 0.f;
-            if (bb >= nb) { src[bb] = special; continue; }             // no such row: never stored
+            if (bb >= nb || t >= T1) { src[bb] = special; continue; }  // no such row / cell: never stored
             if (t == T) {
                 src[bb] = special + E;                                   // REP row                                 (model :58-60)
             } else if (msk[bb] == 1.0f) {
@@ -285,7 +386,57 @@ __global__ __launch_bounds__(128) void psi_embed_event_kernel(const float* __res
                 any_mlp = true;
             }
         }
-        if (v < V && __any(any_mlp)) {
+        // ---- the variable's MLP on the matrix cores, in exact fp32 (PE_NB = 1): out[cell][e] = b4[e] + sum_j w4[e][j] h_j(cell) is a
+        // [cells x 64] x [64 x 24] product per variable.  v_mfma_f32_16x16x4_f32 is bit for bit the ascending-j fmaf chain of the VALU
+        // form below (C-in = b4), so results are unchanged and the fp32 kernel mode needs no second form.  A wave takes the cells of ITS
+        // lanes in groups of 16 (t = 16 g .. 16 g + 15); a lane computes 16 of the group's 16 x 64 hidden activations (2 FMA + max + FMA
+        // each: the A fragments), the second Linear's weights are the B fragments (read once per wave: 32 registers), and the VALU form's
+        // 8 broadcast LDS reads per hidden unit and cell — what bound it (44 us) — are gone.
+        bool mfma_done = false;
+        if constexpr (PE_NB == 1) {
+            if (use_mfma && v < V) {
+                mfma_done = true;
+                const int lane = threadIdx.x & 63, rr = lane & 15, kk = lane >> 4;
+                const int tbase = t & ~63;                                    // first cell of this wave in this pass
+                const unsigned long long need = __ballot(any_mlp);
+                float bw0[16], bw1[16];
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    bw0[ks] = sw4[(4 * ks + kk) * E + rr];
+                    bw1[ks] = rr < E - 16 ? sw4[(4 * ks + kk) * E + 16 + rr] : 0.f;
+                }
+                const float c0 = sb4[rr], c1 = rr < E - 16 ? sb4[16 + rr] : 0.f;
+#pragma unroll 1
+                for (int g = 0; g < 4; ++g) {
+                    if (tbase + 16 * g >= T) break;                            // no time step in this group (wave-uniform)
+                    if (((need >> (16 * g)) & 0xffffull) == 0) continue;       // every cell of the group is an override row
+                    const float vg = __shfl(val[0], 16 * g + rr, 64), ng = __shfl(nob[0], 16 * g + rr, 64);
+                    f32x4 a0 = (f32x4){c0, c0, c0, c0}, a1 = (f32x4){c1, c1, c1, c1};
+#pragma unroll
+                    for (int ks = 0; ks < 16; ++ks) {
+                        const int j = 4 * ks + kk;
+                        const float4 la = *(const float4*)(sl0 + j * 8);
+                        const float hj = fmaf(fmaxf(fmaf(la.x, vg, fmaf(la.y, ng, la.z)), 0.f), la.w, sl0[j * 8 + 4]);   // (as the VALU form below)
+                        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(hj, bw0[ks], a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(hj, bw1[ks], a1, 0, 0, 0);
+                    }
+                    // C layout: column e = rr (+16), rows = cells 4 kk + r of the group
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int tc = tbase + 16 * g + 4 * kk + r;
+                        if (tc < T1) {
+                            tile[tc * E + rr] = a0[r];
+                            if (rr < E - 16) tile[tc * E + 16 + rr] = a1[r];
+                        }
+                    }
+                }
+                // the wave's own LDS operations execute in order: the override rows below (same wave, same cells) land after these
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("" ::: "memory");
+            }
+        }
+        if (!mfma_done && v < V && __any(any_mlp)) {
 #pragma unroll
             for (int bb = 0; bb < PE_NB; ++bb)
 #pragma unroll
@@ -296,25 +447,28 @@ __global__ __launch_bounds__(128) void psi_embed_event_kernel(const float* __res
                 const float lsh = sl0[j * 8 + 4];                        // bn shift
                 float hj[PE_NB];
 #pragma unroll
-                for (int bb = 0; bb < PE_NB; ++bb) hj[bb] = fmaxf(la.x * val[bb] + la.y * nob[bb] + la.z, 0.f) * la.w + lsh;
+                for (int bb = 0; bb < PE_NB; ++bb) hj[bb] = fmaf(fmaxf(fmaf(la.x, val[bb], fmaf(la.y, nob[bb], la.z)), 0.f), la.w, lsh);   // explicit fmaf: both forms round alike
                 const float4* wj = (const float4*)(sw4 + j * E);
 #pragma unroll
                 for (int e4 = 0; e4 < E / 4; ++e4) {
                     const float4 w = wj[e4];
 #pragma unroll
                     for (int bb = 0; bb < PE_NB; ++bb) {
-                        out[bb][4 * e4] += w.x * hj[bb]; out[bb][4 * e4 + 1] += w.y * hj[bb];
-                        out[bb][4 * e4 + 2] += w.z * hj[bb]; out[bb][4 * e4 + 3] += w.w * hj[bb];
+                        out[bb][4 * e4] = fmaf(w.x, hj[bb], out[bb][4 * e4]); out[bb][4 * e4 + 1] = fmaf(w.y, hj[bb], out[bb][4 * e4 + 1]);
+                        out[bb][4 * e4 + 2] = fmaf(w.z, hj[bb], out[bb][4 * e4 + 2]); out[bb][4 * e4 + 3] = fmaf(w.w, hj[bb], out[bb][4 * e4 + 3]);
                     }
                 }
             }
         }
 #pragma unroll
         for (int bb = 0; bb < PE_NB; ++bb) {
-            if (bb >= nb) continue;
+            if (bb >= nb || t >= T1) continue;
             if (src[bb]) {
 #pragma unroll
                 for (int e = 0; e < E; ++e) out[bb][e] = src[bb][e];
+            } else if (mfma_done) {                                 // the cell's row is in the tile already (written by this wave): take it back
+#pragma unroll                                                        // for the psi0 copy, and rewrite it unchanged below
+                for (int e = 0; e < E; ++e) out[bb][e] = tile[(size_t)bb * D + t * E + e];
             }
             if (psi0_out) {                                          // parity checks only: psi0 in the time view, before the add
                 float* d0 = psi0_out + (((size_t)(b0 + bb) * T1 + t) * (V + 1) + v) * E;
@@ -444,7 +598,7 @@ int launch_psi_embed_event_nb(const MedpDuettWeights* w, const float* xs_static,
     psi_embed_event_kernel<24, 64, NB><<<dim3((B + NB - 1) / NB, V1), 128, lds, s>>>(
         xs_ts, (const float*)w->emb_l0, (const float*)w->emb_w4t, (const float*)w->emb_b4, (const float*)w->n_obs_table, w->n_obs_rows, tw,
         (const float*)w->special, (const float*)w->event_embedding, (const float*)w->event_enc[0].g_attn, w->norm_eps, xe, (bf16_t*)h, psi0_out,
-        B, T, V);
+        B, T, V, NB == 1 ? embed_mfma_on() : 0);
     MEDP_LAUNCH_CHECK("duett psi_embed_event");
     return 0;
 }
@@ -574,10 +728,7 @@ extern "C" int medp_duett_encode(const MedpDuettWeights* w, const float* xs_stat
             MEDP_CHECK_ARG(e == hipSuccess, "duett_encode: psi0 copy failed");
         }
     }
-    time_embed_kernel<<<dim3((B * T1 + TE_ROWS - 1) / TE_ROWS, (tt + 255) / 256), 256, TE_ROWS * w->d_hidden_time * sizeof(float), s>>>(
-        xs_times, (const float*)w->time_w0, (const float*)w->time_b0, (const float*)w->time_bn_scale, (const float*)w->time_bn_shift,
-        (const float*)w->time_w3t, (const float*)w->time_b3, (const float*)w->rep_embedding, temb, B, T, w->d_hidden_time, tt);
-    MEDP_LAUNCH_CHECK("duett time_embed");
+    MEDP_TRY(launch_time_embed(w, xs_times, temb, B, T, s));
 
     const float* cur = psi;          // time view [B, T1, V1, E]; rows (b,t) of tt features
     const float* cur_rn = nullptr;   // pending final-ScaleNorm row scales of `cur`
@@ -650,10 +801,7 @@ extern "C" int medp_duett_embed_fwd(const MedpDuettWeights* w, const float* xs_s
     }
     if (stages & 2) {
         MEDP_CHECK_ARG(temb_out, "duett_embed_fwd: stage 2 needs temb_out");
-        time_embed_kernel<<<dim3((B * T1 + TE_ROWS - 1) / TE_ROWS, (tt + 255) / 256), 256, TE_ROWS * w->d_hidden_time * sizeof(float), s>>>(
-            xs_times, (const float*)w->time_w0, (const float*)w->time_b0, (const float*)w->time_bn_scale, (const float*)w->time_bn_shift,
-            (const float*)w->time_w3t, (const float*)w->time_b3, (const float*)w->rep_embedding, temb_out, B, T, w->d_hidden_time, tt);
-        MEDP_LAUNCH_CHECK("duett_embed_fwd(time)");
+        MEDP_TRY(launch_time_embed(w, xs_times, temb_out, B, T, s));
     }
     return 0;
 }
@@ -670,4 +818,12 @@ extern "C" int medp_duett_swap_add_norm(const float* in, const float* rnorm, con
                                         E / 4, (hipStream_t)stream);
     MEDP_CHECK_ARG(rc != 1, "duett_swap_add_norm: rows of more than 6400 floats are not built");
     return rc;
+}
+
+// Debug hook (NOT part of the C ABI in include/medp_hip.h; tests/test_gpu_duett_fused.py): 1 / 0 = the fp32-MFMA / VALU forms of the
+// time-embedding and psi-embedding kernels, -1 = back to the environment's choice.  Returns the previous setting.
+extern "C" int medp_dbg_embed_mfma(int on) {
+    const int prev = g_embed_mfma;
+    g_embed_mfma = on < 0 ? -1 : (on != 0);
+    return prev;
 }

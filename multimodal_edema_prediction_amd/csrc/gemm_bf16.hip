@@ -629,9 +629,36 @@ extern "C" size_t medp_gemm_nt_workspace_bytes(int M, int N, int K) {
     return S > 1 ? (size_t)S * M * N * sizeof(float) : 0;
 }
 
+static int gemm_dispatch(int tag, const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldw, int ldc,
+                         const float* bias, const float* scale, const float* residual, int ldr, int act, int out_bf16,
+                         float* workspace, size_t workspace_bytes, const MedpGemmFold* fold, void* stream);
+
 int medp_gemm_bf16_nt_tagged_ws(int tag, const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldw, int ldc,
                                 const float* bias, const float* scale, const float* residual, int ldr, int act, int out_bf16,
-                                float* workspace, size_t workspace_bytes, void* stream);
+                                float* workspace, size_t workspace_bytes, void* stream) {
+    return gemm_dispatch(tag, A, W, C, M, N, K, lda, ldw, ldc, bias, scale, residual, ldr, act, out_bf16, workspace, workspace_bytes, nullptr, stream);
+}
+
+// the conditions under which gemm_dispatch takes the 256 x 256 tile kernels (v6 / v7): the only ones that carry the LayerNorm fold
+static bool uses_tile256(int M, int N) {
+    static const int force = [] { const char* e = getenv("MEDP_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
+    const int tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
+    return M >= 2048 && N >= 256 && (force == 6 || (force == 0 && tiles256 >= 160));
+}
+
+bool medp_gemm_fold_eligible(int M, int N, int K) {
+    static const int ragged_on = [] { const char* e = getenv("MEDP_GEMM_RAGGED"); return e ? atoi(e) : 0; }();
+    return uses_tile256(M, N) && !ragged_on && K % 64 == 0 && N % 256 == 0;
+}
+
+int medp_gemm_bf16_nt_fold(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldw, int ldc, const float* bias,
+                           const float* scale, const float* residual, int ldr, int act, int out_bf16, const MedpGemmFold& fold, void* stream) {
+    MEDP_CHECK_ARG(medp_gemm_fold_eligible(M, N, K), "gemm(fold): M=%d N=%d K=%d does not take the 256-tile kernels", M, N, K);
+    MEDP_CHECK_ARG(!fold.stats_in || (fold.colsum && fold.ln_dim > 0 && fold.stats_tiles > 0 && fold.stats_tiles <= 4 && out_bf16 && !residual && !scale),
+                   "gemm(fold): a consumer needs colsum, ln_dim, 1..4 stats tiles, a bf16 result and no residual / scale");
+    MEDP_CHECK_ARG(!fold.c2 || (fold.stats_out && !out_bf16 && fold.ldc2 % 4 == 0), "gemm(fold): a producer writes fp32 C, c2 (ld % 4 == 0) and stats_out");
+    return gemm_dispatch(1, A, W, C, M, N, K, lda, ldw, ldc, bias, scale, residual, ldr, act, out_bf16, nullptr, 0, &fold, stream);
+}
 
 int medp_gemm_bf16_nt_tagged(int tag, const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldw, int ldc,
                              const float* bias, const float* scale, const float* residual, int ldr, int act, int out_bf16,
@@ -639,9 +666,9 @@ int medp_gemm_bf16_nt_tagged(int tag, const void* A, const void* W, void* C, int
     return medp_gemm_bf16_nt_tagged_ws(tag, A, W, C, M, N, K, lda, ldw, ldc, bias, scale, residual, ldr, act, out_bf16, nullptr, 0, stream);
 }
 
-int medp_gemm_bf16_nt_tagged_ws(int tag, const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldw, int ldc,
-                                const float* bias, const float* scale, const float* residual, int ldr, int act, int out_bf16,
-                                float* workspace, size_t workspace_bytes, void* stream) {
+static int gemm_dispatch(int tag, const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldw, int ldc,
+                         const float* bias, const float* scale, const float* residual, int ldr, int act, int out_bf16,
+                         float* workspace, size_t workspace_bytes, const MedpGemmFold* fold, void* stream) {
     MEDP_CHECK_ARG(A && W && C, "gemm: null operand");
     MEDP_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
     MEDP_CHECK_ARG(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0, "gemm: K, lda, ldw must be multiples of 8 (16-B chunks)");
@@ -670,11 +697,12 @@ int medp_gemm_bf16_nt_tagged_ws(int tag, const void* A, const void* W, void* C, 
     const int tiles_v3 = ((M + 255) / 256) * ((N + 127) / 128);
     const bool use_v3 = force == 3 || (force == 0 && M >= 2048 && N >= 256 && tiles_v3 >= v3_min_tiles);
     MedpGemmArgs a4{A, W, C, M, N, K, lda, ldw, ldc, bias, scale, residual, ldr, act, out_bf16, nullptr, 0};
+    if (fold) a4.fold = *fold;
     if (N <= 64) return launch<128, 64, 0>(p, s);
     // v6 (256 x 256 x 64, 8 waves ping-pong, gemm_bf16_v6.hip) runs ONE workgroup per CU: default once there are enough
     // 256^2 tiles to occupy most of the chip (the CXR-encoder shapes: 195 / 585 / 780 tiles); v3 keeps the smaller grids
-    const int tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
-    const bool use_v6 = M >= 2048 && N >= 256 && (force == 6 || (force == 0 && tiles256 >= 160));
+    const bool use_v6 = uses_tile256(M, N);
+    MEDP_CHECK_ARG(!fold || use_v6, "gemm(fold): shape does not take the 256-tile kernels");
     // v7: the same K-loop, persistent over the tile list, where the grid is more than one round of workgroups (qkv, fc1)
     static const int v7_on = [] { const char* e = getenv("MEDP_GEMM_V7"); return e ? atoi(e) : 1; }();
     const bool use_v7 = use_v6 && force != 6 && v7_on && medp_gemm_v7_eligible(a4);

@@ -40,7 +40,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 }
 
 constexpr int BM = 256, BN = 256, HALF = 128 * 128, KBUF = 4 * HALF;   // 16 KiB half-tile, 64 KiB K-tile buffer
-constexpr int LDS_MAIN = 2 * KBUF, LDS_EPI = 8 * 64 * 68 * 4, LDS_BYTES = LDS_EPI > LDS_MAIN ? LDS_EPI : LDS_MAIN;
+constexpr int LDS_MAIN = 2 * KBUF, LDS_EPI = 8 * 64 * 68 * 4;
+constexpr int LDS_STATS = LDS_EPI;                         // LayerNorm-fold producer: [256 rows][4 column waves][2] floats behind the epilogue patches
+constexpr int LDS_BYTES = LDS_STATS + 256 * 4 * 2 * 4;
+static_assert(LDS_BYTES >= LDS_MAIN && LDS_BYTES <= 160 * 1024, "v6 LDS plan");
 
 // patch write -> read (and read -> next write) inside ONE wave: the LDS executes a wave's operations in order, only the
 // compiler must not reorder them.  (A workgroup-scope fence here also emits vmcnt(0): the second half of the epilogue would
@@ -262,6 +265,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v6_kernel(const MedpGemmA
     };
     const bool has_res = p.residual != nullptr;
     if (has_res) load_res(0);
+    // LayerNorm fold (gemm_variants.h).  Consumer: the row's mean / rstd from the producer's per-tile partial sums, summed in tile order;
+    // C = rstd acc - rstd mean colsum + bias.  Producer: bf16 copy of the fp32 result + this tile's (sum, sum of squares) per row.
+    const MedpGemmFold& fo = p.fold;
+    const bool consumer = fo.stats_in != nullptr, producer = fo.c2 != nullptr;
+    f32x4 cs4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (consumer && n < p.N) cs4 = *(const f32x4*)(fo.colsum + n);
+    const float inv_dim = consumer ? 1.0f / (float)fo.ln_dim : 0.f;
+    float* sst = (float*)(smem + LDS_STATS);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -275,8 +286,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v6_kernel(const MedpGemmA
             const int rr = it * 4 + er;
             const int m = m0 + wm * 128 + half * 64 + rr;
             f32x4 v = *(const f32x4*)(wl + rr * 68 + ec);
+            float s1 = 0.f, s2 = 0.f;
             if (m < p.M && n < p.N) {
-                v += bias4;
+                if (consumer) {
+                    float a1 = 0.f, a2 = 0.f;
+                    for (int t = 0; t < fo.stats_tiles; ++t) {
+                        const float2 st = *(const float2*)(fo.stats_in + ((size_t)m * fo.stats_tiles + t) * 2);
+                        a1 += st.x;
+                        a2 += st.y;
+                    }
+                    const float mean = a1 * inv_dim;
+                    const float rstd = rsqrtf(fmaxf(a2 * inv_dim - mean * mean, 0.f) + fo.ln_eps);
+                    v = v * rstd - (mean * rstd) * cs4 + bias4;
+                } else {
+                    v += bias4;
+                }
                 if (p.act == 1) v = p.out_bf16 ? gelu_bf16_4(v) : gelu_erf4(v);
                 v *= scale4;
                 if (has_res) v += res[half][it];
@@ -290,9 +314,38 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v6_kernel(const MedpGemmA
                 } else {
                     __builtin_nontemporal_store(v, (f32x4*)((float*)p.C + (size_t)m * p.ldc + n));
                 }
+                if (producer) {
+                    uint2 o;
+                    o.x = pack_bf2(v[0], v[1]);
+                    o.y = pack_bf2(v[2], v[3]);
+                    *(uint2*)((bf16_t*)fo.c2 + (size_t)m * fo.ldc2 + n) = o;          // read next by the consumer GEMM: default cache policy
+                    s1 = (v[0] + v[1]) + (v[2] + v[3]);
+                    s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                }
+            }
+            if (producer) {                         // the row's 64 columns of this wave: butterfly over the 16 lanes that share it
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) {
+                    s1 += __shfl_xor(s1, d, 64);
+                    s2 += __shfl_xor(s2, d, 64);
+                }
+                if ((lane & 15) == 0) *(float2*)(sst + ((wm * 128 + half * 64 + rr) * 4 + wn) * 2) = make_float2(s1, s2);
             }
         }
         MEDP_WAVE_LDS_SYNC();
+    }
+    if (producer) {                                 // the four column waves' partials of a row, added in wave order: one (sum, sum sq) per row and tile
+        __syncthreads();
+        if (tid < 256 && m0 + tid < ((p.M + 255) & ~255)) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float2 st = *(const float2*)(sst + (tid * 4 + q) * 2);
+                a1 += st.x;
+                a2 += st.y;
+            }
+            *(float2*)(fo.stats_out + ((size_t)(m0 + tid) * tiles_n + n0 / BN) * 2) = make_float2(a1, a2);
+        }
     }
     if (slot && tid == 0) {
         const unsigned left = __hip_atomic_fetch_add(slot + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

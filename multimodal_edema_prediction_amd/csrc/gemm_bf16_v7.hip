@@ -44,7 +44,9 @@ constexpr int PATCH = 16 * PROW;                                       // one wa
 constexpr int MAILBOX = 2 * KBUF + 8 * PATCH;                          // the next tile index, written by wave 0
 constexpr int BIASBUF = MAILBOX + 256;                                 // 2 x 256 floats: bias slice of this / the next tile
 constexpr int TRACEBUF = BIASBUF + 2048;                               // debug timeline (medp_dbg_gemm_v7_trace): 8 tiles x 5 x u64
-constexpr int LDS_BYTES = TRACEBUF + 512;
+constexpr int STATBUF = TRACEBUF + 512;                                // LayerNorm fold (consumer): this tile's [256 rows][<= 4 tiles][2] raw row sums
+constexpr int CSBUF = STATBUF + 256 * 4 * 2 * 4;                       // 2 x 256 floats: colsum(W g) slice of this / the next tile
+constexpr int LDS_BYTES = CSBUF + 2048;
 static_assert(LDS_BYTES <= 160 * 1024, "K buffers + patches + mailbox exceed the LDS");
 constexpr int NWG = 256;                                               // resident workgroups = CUs of an MI355X
 
@@ -78,7 +80,9 @@ constexpr int NWG = 256;                                               // reside
 #define PT(k) do { } while (0)
 #endif
 
-template <int TAG>
+// FOLD: the LayerNorm-fold CONSUMER epilogue (gemm_variants.h) — its own instantiation, so that the plain kernel's register
+// allocation (251 of 256 VGPRs, no spill) is untouched by it
+template <int TAG, bool FOLD = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v7_kernel(const MedpGemmArgs p, unsigned* slot, unsigned long long* trace, const int MB, const int SN) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -237,9 +241,31 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v7_kernel(const MedpGemmA
         }
     };
     int bias_cur = 0;
+    // LayerNorm fold, consumer side (gemm_variants.h): the column sums of W g travel like the bias (wave 1); the producer's raw row sums of
+    // the tile's 256 rows (stats_in is padded to whole tiles) are one flat copy of 256 x tiles x 8 bytes, 1 KB per wave.  Single-buffered:
+    // issued right behind a tile-top barrier — every wave has then left the previous epilogue, the only reader — and retired long before
+    // this tile's epilogue (the K-loop's first counted wait, P2 of K-tile 1, leaves only the 10 youngest pieces in flight: 12 follow it).
+    const MedpGemmFold& fo = p.fold;
+    constexpr bool consumer = FOLD;
+    // (`opaque`: lane-constant address parts computed where they are used — hoisted out of the tile loop they stay live through the
+    //  K-loop, which has 5 VGPRs to spare, and are spilled)
+    auto opaque = [](int x) { asm volatile("" : "+v"(x)); return x; };
+    auto stage_cs = [&](int nn, bool live, int which) {
+        if (consumer && wave == 1) {
+            const int nj = nn + opaque(lane) * 4;
+            const float* src = (live && nj < p.N) ? fo.colsum + nj : (const float*)zero;
+            glds16(src, smem + CSBUF + which * 1024);
+        }
+    };
+    auto stage_stats = [&](int mm) {
+        if (consumer && wave * 1024 < 256 * fo.stats_tiles * 8)
+            glds16((const char*)fo.stats_in + (size_t)mm * fo.stats_tiles * 8 + wave * 1024 + opaque(lane) * 16, smem + STATBUF + wave * 1024);
+    };
 
     // prologue of the FIRST tile: K-tile 0 and K-tile 1 complete — the state every later tile starts from
     stage_bias(n0, true, 0);
+    stage_cs(n0, true, 0);
+    stage_stats(m0);
     draw_ticket();
     stage_a(0, 0, 0); stage_w(0, 0, 0); stage_w(0, 0, 1); stage_a(0, 0, 1);        // the order of the steady-state stream
     stage_a(64, 1, 0); stage_w(64, 1, 0); stage_w(64, 1, 1);                        // (A rows 64-127 of K-tile 1: P1 of K-tile 0)
@@ -269,6 +295,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v7_kernel(const MedpGemmA
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){z, z, z, z};
         if (first) read_w(smem, 0, fw0a);      // later tiles: read in P4 of the previous tile's last K-tile
+        else stage_stats(m0);                  // (the first tile's were staged by the prologue)
         first = false;
         if (wm == 1) MEDP_BAR();       // group 1 runs one barrier behind (group 0 pays its extra barrier after the loop)
 
@@ -350,23 +377,47 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v7_kernel(const MedpGemmA
         stamp(1, 0);
         draw_ticket();
         stage_bias(n0n, t_next >= 0, bias_cur ^ 1);
+        stage_cs(n0n, t_next >= 0, bias_cur ^ 1);
 
         // ---- epilogue: bias / GELU / bf16 pack on the accumulator layout (a lane holds 4 consecutive columns of one row), then a
         // 16-row x 64-column bf16 patch per wave through LDS so that every global store instruction writes whole 128-B rows
         f32x4 bj[4];
+        if constexpr (!FOLD) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bj[j] = *(const f32x4*)(smem + BIASBUF + bias_cur * 1024 + (wn * 64 + j * 16 + kq * 4) * 4);
+            for (int j = 0; j < 4; ++j) bj[j] = *(const f32x4*)(smem + BIASBUF + bias_cur * 1024 + (wn * 64 + j * 16 + kq * 4) * 4);
+        }
         char* wl = smem + 2 * KBUF + wave * PATCH;
         const bool full_tile = m0 + BM <= p.M && n0 + BN <= p.N;
         const int prow = lane >> 3, pchunk = lane & 7;
         const int ncol = n0 + wn * 64 + pchunk * 8;
         typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
         typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+        const float inv_dim = consumer ? 1.0f / (float)fo.ln_dim : 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
+            float rstd = 1.f, mr = 0.f;
+            if constexpr (consumer) {          // the row's mean / rstd from its per-tile (sum, sum of squares), added in tile order
+                const float* sr = (const float*)(smem + STATBUF) + (wm * 128 + i * 16 + opaque(fr)) * fo.stats_tiles * 2;
+                float a1 = 0.f, a2 = 0.f;
+                for (int t = 0; t < fo.stats_tiles; ++t) {
+                    const float2 st = *(const float2*)(sr + 2 * t);
+                    a1 += st.x;
+                    a2 += st.y;
+                }
+                const float mean = a1 * inv_dim;
+                rstd = rsqrtf(fmaxf(a2 * inv_dim - mean * mean, 0.f) + fo.ln_eps);
+                mr = mean * rstd;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                f32x4 v = acc[i][j] + bj[j];
+                f32x4 v;
+                if constexpr (consumer) {      // (bias and column sums are re-read per element group: 32 registers less than holding them across i)
+                    const f32x4 cj = *(const f32x4*)(smem + CSBUF + bias_cur * 1024 + (wn * 64 + j * 16 + kq * 4) * 4);
+                    const f32x4 bb = *(const f32x4*)(smem + BIASBUF + bias_cur * 1024 + (wn * 64 + j * 16 + kq * 4) * 4);
+                    v = acc[i][j] * rstd - mr * cj + bb;
+                } else {
+                    v = acc[i][j] + bj[j];
+                }
                 if (p.act == 1) v = gelu_bf16_4(v);
                 *(u32x2*)(wl + fr * PROW + j * 32 + kq * 8) = (u32x2){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
             }
@@ -446,10 +497,10 @@ unsigned* ticket_block(hipStream_t stream) {
     return slots + (size_t)s * SLOT_WORDS;
 }
 
-template <int TAG>
+template <int TAG, bool FOLD>
 int launch_v7(const MedpGemmArgs& a, hipStream_t stream) {
     MEDP_ONCE_PER_DEVICE({
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_v7_kernel<TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_v7_kernel<TAG, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     });
     unsigned* slot = ticket_block(stream);
     if (!slot) return -1;                                  // out of private blocks: the caller falls back to v6
@@ -474,7 +525,7 @@ int launch_v7(const MedpGemmArgs& a, hipStream_t stream) {
     static const int env_sn = [] { const char* e = getenv("MEDP_V7_BLOCK"); const char* x = e ? strchr(e, 'x') : nullptr; return x ? atoi(x + 1) : 0; }();
     int mb = 8, sn = 4;
     if (env_mb > 0 && env_sn > 0) { mb = env_mb; sn = env_sn; }
-    gemm_bf16_nt_v7_kernel<TAG><<<nwg, 512, LDS_BYTES, stream>>>(a, slot, g_trace, mb, sn);
+    gemm_bf16_nt_v7_kernel<TAG, FOLD><<<nwg, 512, LDS_BYTES, stream>>>(a, slot, g_trace, mb, sn);
     MEDP_LAUNCH_CHECK("medp_gemm_bf16_nt(v7)");
     return 0;
 }
@@ -489,7 +540,8 @@ bool medp_gemm_v7_eligible(const MedpGemmArgs& a) {
 
 // returns -1 when no private ticket block is left (caller launches v6 instead)
 int medp_gemm_v7_launch(const MedpGemmArgs& a, int tag, void* stream) {
-    return tag == 1 ? launch_v7<1>(a, (hipStream_t)stream) : launch_v7<0>(a, (hipStream_t)stream);
+    if (a.fold.stats_in) return launch_v7<1, true>(a, (hipStream_t)stream);        // (the fold exists for the tagged encoder GEMMs only)
+    return tag == 1 ? launch_v7<1, false>(a, (hipStream_t)stream) : launch_v7<0, false>(a, (hipStream_t)stream);
 }
 
 unsigned* medp_gemm_ticket_block(void* stream) { return ticket_block((hipStream_t)stream); }

@@ -134,6 +134,14 @@ class Dinov2Backbone(nn.Module):
             L.fc1_w, L.fc1_b = ptr(bf(sd[p + "mlp.fc1.weight"])), ptr(f32(sd[p + "mlp.fc1.bias"]))
             L.fc2_w, L.fc2_b = ptr(bf(sd[p + "mlp.fc2.weight"])), ptr(f32(sd[p + "mlp.fc2.bias"]))
             L.ls2 = ptr(f32(sd[p + "layer_scale2.lambda1"]))
+            # LayerNorm fold operands (include/medp_hip.h): W g in bf16, the row sums of THAT rounded matrix, b + W beta
+            for name, W, b, g, beta in (("qkv", qkv_w, qkv_b, sd[p + "norm1.weight"], sd[p + "norm1.bias"]),
+                                        ("fc1", sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"], sd[p + "norm2.weight"], sd[p + "norm2.bias"])):
+                W32 = W.detach().to(torch.float32)
+                wg = bf(W32 * g.detach().to(torch.float32)[None, :])
+                setattr(L, name + "_wg", ptr(wg))
+                setattr(L, name + "_cs", ptr(f32(wg.to(torch.float32).sum(dim=1))))
+                setattr(L, name + "_b2", ptr(f32(b.detach().to(torch.float32) + W32 @ beta.detach().to(torch.float32))))
         w = MedpVitWeights()
         w.hidden, w.n_layers, w.n_heads, w.mlp_hidden = D, c.num_hidden_layers, c.num_attention_heads, D * c.mlp_ratio
         w.patch, w.pos_side, w.patch_kpad, w.ln_eps = c.patch_size, c.image_size // c.patch_size, kpad, c.layer_norm_eps

@@ -61,6 +61,57 @@ def test_embed_stage_against_oracle(B, T, V):
     assert torch.equal(h, Fn.scalenorm(xe, m.event_transformers[0].layers[0][0][0].g))               # == the separate launch, bit for bit
 
 
+@pytest.mark.parametrize("B,T,V", [(8, 32, 16), (6, 96, 48), (2, 140, 20)])
+def test_embed_stage_mfma_form_is_bit_identical_to_the_valu_form(B, T, V, request):
+    """The psi / time embeddings on the matrix cores in exact fp32 (`v_mfma_f32_16x16x4_f32`: a k-ordered fmaf chain) against the
+    VALU kernels they replace: every output element bit for bit — psi0, the event-view rows, their bf16 ScaleNorm, the time
+    embedding — on batches with masked time steps, masked events (SSL), over-length rows (T + 1 > 128: several passes of the cell
+    loop) and the REP row.  So the fp32 kernel mode needs no second form (medp_dbg_embed_mfma switches at run time)."""
+    from multimodal_edema_prediction_amd.main_architecture_duett import load_duett_backbone
+    DS, E = 8, 24
+    torch.manual_seed(3)
+    m = load_duett_backbone("synthetic", d_static_num=DS, d_time_series_num=V, n_timesteps=T, freeze=True)
+    with torch.no_grad():
+        for n, b in m.named_buffers():
+            if n.endswith("running_mean"):
+                b.copy_(0.1 * torch.randn_like(b))
+            elif n.endswith("running_var"):
+                b.copy_(0.5 + torch.rand_like(b))
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(11)
+    obs = torch.rand(B, T, V, generator=g) < 0.3
+    xs_ts = torch.zeros(B, T, 2 * V + 1)
+    xs_ts[:, :, :V] = torch.randn(B, T, V, generator=g) * obs
+    xs_ts[:, :, V:2 * V] = obs.float() * torch.randint(1, 20, (B, T, V), generator=g).float()      # counts above the table: clipped
+    xs_ts[:, :, V:2 * V][torch.rand(B, T, V, generator=g) < 0.05] = -1.0                            # masked events (SSL)
+    xs_ts[:, :, 2 * V] = (torch.rand(B, T, generator=g) < 0.15).float()                            # masked time steps
+    xs_ts[0, :, 2 * V] = 1.0                                                                         # a sample with every step masked
+    xs_static, xs_times = torch.randn(B, DS, generator=g), torch.rand(B, T, generator=g) * 4
+    xs_ts, xs_static, xs_times = xs_ts.to(DEV), xs_static.to(DEV), xs_times.to(DEV)
+    w = m._prepare()[0]
+    T1, V1 = T + 1, V + 1
+    L = lib()
+    prev = L.medp_dbg_embed_mfma(1)
+    request.addfinalizer(lambda: L.medp_dbg_embed_mfma(prev))
+
+    def run(on):
+        L.medp_dbg_embed_mfma(on)
+        xe = torch.full((B, V1, T1 * E), float("nan"), device=DEV)
+        h = torch.zeros((B, V1, T1 * E), device=DEV, dtype=torch.bfloat16)
+        temb = torch.full((B, T1, V1 * E), float("nan"), device=DEV)
+        p0 = torch.full((B, T1, V1, E), float("nan"), device=DEV)
+        tab = torch.empty((B, E), device=DEV)
+        check(L.medp_duett_embed_fwd(ctypes.byref(w), ptr(xs_static), ptr(xs_ts), ptr(xs_times), B, T, ptr(xe), ptr(h), ptr(temb), ptr(p0),
+                                     ptr(tab), 3, stream()), "duett_embed_fwd")
+        torch.cuda.synchronize()
+        return xe, h, temb, p0
+
+    a, b_ = run(1), run(0)
+    for name, x, y in zip(("xe", "h", "temb", "psi0"), a, b_):
+        assert not torch.isnan(x.float()).any(), name
+        assert torch.equal(x, y), f"{name}: {int((x != y).sum())} elements differ, max {float((x.float() - y.float()).abs().max()):.3e}"
+
+
 @pytest.mark.parametrize("B,A1,A2", [(3, 33, 17), (4, 97, 49), (2, 49, 97), (1, 257, 97)])
 @pytest.mark.parametrize("pending_norm,batched_add", [(False, False), (True, True)])
 def test_swap_add_norm(B, A1, A2, pending_norm, batched_add):

@@ -9,6 +9,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from multimodal_edema_prediction_amd import functional as Fn  # noqa: E402
+from multimodal_edema_prediction_amd.abi import lib  # noqa: E402
 
 DEV = "cuda"
 
@@ -178,7 +179,7 @@ def test_attn_dh64_forced_rescale():
 
 
 @pytest.mark.parametrize("case", ["late_key", "key256", "cls_query", "cls_key", "ramp"])
-def test_attn_dh64_s257_rescale_paths(case):
+def test_attn_dh64_s257_rescale_paths(case, request):
     """The S = 257 kernel (one workgroup per (batch, head), online softmax initialised from key 256, deferred rescale, class query
     split over the waves): inputs that FORCE each data-dependent path (cdna guide rule 26) against fp64, every row checked, plus the
     log-sum-exp the backward consumes.
@@ -187,18 +188,24 @@ def test_attn_dh64_s257_rescale_paths(case):
       cls_query: the class query has a dominant key inside ONE wave's key slice -> the 8-way partial combine must rescale
       cls_key  : key 0 dominates every query
       ramp     : scores grow by a few units per block: growth both below and above the defer threshold"""
-    B, S, H = 2, 257, 2
+    B, S, H = 2, 257, 3
     D = H * 64
+    # 6 (b, h) on a pretended 4 resident slots: 4 whole units (two subtiles per wave) + 2 x 2 HALF units (one subtile per wave) — the
+    # arrangement B x H = 768 gets on the real 512 slots; both kernels see every forced path
+    prev = lib().medp_dbg_attn_s257_slots(4)
+    request.addfinalizer(lambda: lib().medp_dbg_attn_s257_slots(prev))
     qkv = bf_round(rnd(B * S, 3 * D, seed=23) * 0.5)
     x = qkv.view(B, S, 3, H, 64)
     if case == "late_key":
         x[0, 250, 1, 0] = bf_round(x[0, 37, 0, 0] * 30)
         x[1, 200, 1, 1] = bf_round(x[1, 256, 0, 1] * 30)
+        x[1, 255, 1, 2] = bf_round(x[1, 140, 0, 2] * 30)            # (b 1, h 2) runs as half units
     elif case == "key256":
         x[:, 256, 1] = bf_round(x[:, 5, 0] * 12)
     elif case == "cls_query":
         x[0, 100, 1, 0] = bf_round(x[0, 0, 0, 0] * 25)
         x[1, 256, 1, 1] = bf_round(x[1, 0, 0, 1] * 25)
+        x[1, 77, 1, 2] = bf_round(x[1, 0, 0, 2] * 25)
     elif case == "cls_key":
         x[:, 0, 1] = bf_round(x[:, 0, 1] * 6)
     else:
