@@ -323,12 +323,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_v6_kernel(const MedpGemmA
                     s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
                 }
             }
-            if (producer) {                         // the row's 64 columns of this wave: butterfly over the 16 lanes that share it
-#pragma unroll
-                for (int d = 1; d < 16; d <<= 1) {
-                    s1 += __shfl_xor(s1, d, 64);
-                    s2 += __shfl_xor(s2, d, 64);
-                }
+            if (producer) {                         // the row's 64 columns of this wave: butterfly over the 16 lanes (one DPP row) that share it
+                // DPP operands (VALU rate), not __shfl_xor (ds_bpermute: an LDS round trip per step): quad xor 1, quad xor 2, then the two
+                // mirrors — after the quad steps all four lanes of a quad agree, so mirroring pairs quads / halves
+                auto row16_sum = [](float x) {
+                    x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+                    x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+                    x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));    // row_half_mirror
+                    x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));    // row_mirror
+                    return x;
+                };
+                s1 = row16_sum(s1);
+                s2 = row16_sum(s2);
                 if ((lane & 15) == 0) *(float2*)(sst + ((wm * 128 + half * 64 + rr) * 4 + wn) * 2) = make_float2(s1, s2);
             }
         }

@@ -4,14 +4,19 @@
 // Data layout in HBM: residual stream x fp32 [B*S, hidden]; every GEMM input is bf16 written by the producing
 // kernel (LayerNorm / GELU epilogue / attention); LayerScale and the residual add are fused in GEMM epilogues.
 //
-// LayerNorm fold (default for batches whose block GEMMs take the 256 x 256 tile kernels; MEDP_VIT_LNFOLD=0 switches it off): the 24
-// LayerNorm launches of the block loop (a 76-MB pass each: 0.37 ms of a 4.4-ms encoder at B = 64) are folded into the GEMMs on both
-// sides of them.  proj / fc2 — which write the fp32 token stream x anyway — also write bf16(x) and per row and 256-column tile the
+// LayerNorm fold (MEDP_VIT_LNFOLD=1; OFF by default — measured, see below; for batches whose block GEMMs take the 256 x 256 tile
+// kernels): the 24 LayerNorm launches of the block loop (a 76-MB pass each: 0.37 ms of a 4.4-ms encoder at B = 64) are folded into the
+// GEMMs on both sides of them.  proj / fc2 — which write the fp32 token stream x anyway — also write bf16(x) and per row and 256-column tile the
 // (sum, sum of squares) of x; qkv / fc1 multiply bf16(x) by W g and their epilogue applies
 //     LN(x) W^T + b = rstd (x (W g)^T) - rstd mean colsum(W g) + (b + W beta)
 // with mean / rstd from the three partial sums of the row (gemm_variants.h).  x stays fp32; what changes is WHICH bf16 rounding the
 // GEMM operand carries (x instead of LN(x): the same relative precision per element).  The first block's statistics come from one
 // extra pass over x (rowstats_cast_kernel), the final LayerNorm stays a launch.
+// Measured (round 3, tools/bench_gemm_fold.py, profiles/r03_ab_experiments.txt): alone, the four GEMMs of a block cost +21 us with the
+// fold epilogues (qkv +3.2, proj +6.2, fc1 +8.4: its GELU epilogue is VALU-bound already, fc2 +3.5) against 2 x 13.7 us of LayerNorm +
+// their launch gaps — a gain of ~10 us per block; INSIDE the step the same epilogues cost +38 us per block (the side branch competes
+// for exactly the VALU / HBM time they add) and the step is 0.4 % SLOWER (teacher 5.351 / 5.356 ms with, 5.327 / 5.331 without; student
+// 7.639 vs 7.601).  Correct and tested (tests/test_gpu_vit_lnfold.py), not faster: off.
 #include <stdlib.h>
 
 #include "common.h"
@@ -79,7 +84,7 @@ VitWs plan(const MedpVitWeights* w, int B, int H, int W) {
 
 int g_vit_lnfold = -1;          // medp_dbg_vit_lnfold (tests): 1 / 0 force the fold on / off, -1 the environment's choice
 bool fold_wanted(const MedpVitWeights* w, int M) {
-    static const int env_on = [] { const char* e = getenv("MEDP_VIT_LNFOLD"); return e ? atoi(e) : 1; }();
+    static const int env_on = [] { const char* e = getenv("MEDP_VIT_LNFOLD"); return e ? atoi(e) : 0; }();
     const int on = g_vit_lnfold >= 0 ? g_vit_lnfold : env_on;
     const int D = w->hidden;
     if (!on || D % 256 != 0 || D / 256 > 4 || w->n_layers <= 0) return false;

@@ -202,6 +202,39 @@ class ScaleNormFn(torch.autograd.Function):
         return dx, dg, None
 
 
+class ResidualScaleNormFn(torch.autograd.Function):
+    """(x, ScaleNorm(x)) with the residual join folded into the backward: an encoder's x feeds BOTH the residual of the next Linear and
+    the ScaleNorm in front of it, so autograd used to sum the two gradient branches with a torch `add` (12 launches of an 88-MB pass per
+    student step, profiles/r02_kerneltrace_bench_student.txt).  Here the residual branch's gradient arrives as the gradient of the first
+    output and `medp_scalenorm_bwd` ACCUMULATES the norm branch into it (accumulate_dx = 1): one pass less per join, no torch kernel.
+    The incoming tensor is updated in place: in this chain it is the `dy` a Linear's backward hands through to its residual input,
+    produced by the ScaleNorm backward one block up and referenced by nobody else."""
+
+    @staticmethod
+    def forward(ctx, x, g, eps):
+        xc = x.contiguous()
+        y, rn = Fn.scalenorm(xc, g, eps, out_dtype=F32, save_rnorm=True)
+        ctx.save_for_backward(xc, g, rn)
+        return xc.view_as(xc), y
+
+    @staticmethod
+    def backward(ctx, d_pass, dy):
+        x, g, rn = ctx.saved_tensors
+        if dy is None:
+            return d_pass, None, None
+        if d_pass is None or not d_pass.is_contiguous() or d_pass.dtype != F32:
+            dx, dg = Fn.scalenorm_bwd(dy.contiguous(), x, g, rn, need_dg=True)
+            return (dx if d_pass is None else dx + d_pass), dg, None
+        dy2, x2 = dy.contiguous().view(-1, x.shape[-1]), x.view(-1, x.shape[-1])
+        rows, D = x2.shape
+        dg = torch.empty(1, dtype=F32, device=x.device)
+        ws = torch.empty(rows, dtype=F32, device=x.device)
+        check(lib().medp_scalenorm_bwd(ptr(dy2), D, ptr(x2), D, ptr(g), ptr(rn), ptr(d_pass), D, 1, ptr(dg), ptr(ws), rows, D, stream()),
+              "scalenorm_bwd(accumulate)")
+        return d_pass, dg, None
+
+
+_FOLD_RESIDUAL_ADD = __import__("os").environ.get("MEDP_DUETT_FOLD_RESIDUAL_ADD", "1") == "1"
 _MFMA_ATTN = __import__("os").environ.get("MEDP_DUETT_TRAIN_MFMA_ATTN", "1") == "1"
 
 
@@ -284,11 +317,13 @@ def encoder_training(m, x, eps, final_norm, training, seed, sid):
     """One x_transformers-style encoder block (see oracle/xt_encoder.py) on x [B, N, D]."""
     a, ff = m.layers[0][1], m.layers[1][1].ff
     p = float(m.dropout) if training else 0.0
-    h = ScaleNormFn.apply(x, m.layers[0][0][0].g, eps)
+    norm = (lambda t, g: ResidualScaleNormFn.apply(t, g, eps)) if (_FOLD_RESIDUAL_ADD and x.requires_grad) else \
+        (lambda t, g: (t, ScaleNormFn.apply(t, g, eps)))
+    x, h = norm(x, m.layers[0][0][0].g)
     qkv = A.linear(h, torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight], 0))
     o = SelfAttnQKVFn.apply(qkv, m.heads, p, seed, sid)
     x = A.linear(o, a.to_out.weight, None, residual=x)
-    h = ScaleNormFn.apply(x, m.layers[1][0][0].g, eps)
+    x, h = norm(x, m.layers[1][0][0].g)
     f = A.linear(h, ff[0][0].weight, ff[0][0].bias)
     f = A.gelu_dropout(f, p, seed, sid + 1)
     x = A.linear(f, ff[2].weight, ff[2].bias, residual=x)
