@@ -620,7 +620,12 @@ static int splitk_slices(int M, int N, int K) {
     const int nkt = (K + 63) / 64;
     if (force >= 0) return max(1, min(force, nkt));
     if (tiles >= 128 || nkt < 8) return 1;
-    return max(1, min(min(256 / tiles, nkt / 4), 16));
+    // Round-3 sweep (tools/bench_gemm_splitk.py, profiles/r03_ab_experiments.txt): below 64 tiles the slices should fill the chip
+    // (event / time qkv: 33.5 -> 15.8 us, 19.4 -> 15.3); between 64 and 127 tiles a split pays only for a long K (event ff1, 100 tiles x
+    // 37 K-tiles: 36.3 / 28.1 / 25.6 / 25.6 / 29.6 us at 1 / 2 / 3 / 4 / 6 slices) and costs for a short one (ts_proj, 96 tiles x 18
+    // K-tiles: 19.5 us unsplit, 22.3 with 2 slices).
+    if (tiles < 64) return max(1, min(min(256 / tiles, nkt / 4), 16));
+    return nkt >= 32 ? max(1, min(384 / tiles, nkt / 8)) : 1;
 }
 
 extern "C" size_t medp_gemm_nt_workspace_bytes(int M, int N, int K) {
