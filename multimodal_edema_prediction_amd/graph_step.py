@@ -155,6 +155,16 @@ class _GraphedStep:
         from . import autograd_ops as _A
         self._prep_refs = [(m, m._prep) for root in self._stateful_modules() for m in root.modules() if getattr(m, "_prep", None) is not None]
         self._cache_refs = [v for slot in _A._W_CACHE.values() for v in slot.values()]
+        # ... and into the modules' workspaces and pointer / length tables: an eager call with a larger batch or image
+        # REPLACES a workspace (cxr.Dinov2Backbone._ws[slot], duett.Model._ws), the 16-entry table cache of feats_to_input evicts.
+        # Holding what the capture saw keeps that memory allocated, so a replay after such a call still reads and writes live buffers
+        # of its own (the eager call got new ones) instead of freed memory.
+        self._keepalive = []
+        for root in self._stateful_modules():
+            for m in root.modules():
+                ws = m.__dict__.get("_ws")
+                self._keepalive += list(ws.values()) if isinstance(ws, dict) else ([ws] if torch.is_tensor(ws) else [])
+                self._keepalive += list(m.__dict__.get("_tables", {}).values())
 
     def _check_frozen_unchanged(self):
         for m, prep in self._prep_refs:

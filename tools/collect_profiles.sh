@@ -32,6 +32,7 @@ for cfg in teacher student; do
   } > $O/${TAG}_kerneltrace_bench_$cfg.txt
   if [ $cfg = teacher ]; then      # the trace's GEMM mean and the SAME run's in-kernel launch clocks side by side (bench.py reads it back)
     python3 $R/tools/make_profile_json.py gemm $O/${TAG}_kt_$cfg $O/${TAG}_kt_$cfg.log $O/${TAG}_rocprof_gemm.json $TAG
+    python3 $R/tools/prof_by_grid.py $O/${TAG}_kt_$cfg gemm_bf16_nt_v > $O/${TAG}_gemm_by_grid.txt 2>/dev/null || true
   fi
   head -12 $O/${TAG}_kerneltrace_bench_$cfg.txt
   rm -rf $O/${TAG}_kt_$cfg

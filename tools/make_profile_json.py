@@ -10,7 +10,7 @@
       /opt/skills/guides/MI355X_MICROARCH.md), WRITE_SIZE as is, KiB -> bytes; per kernel and launch-weighted mean."""
 import collections, csv, datetime, glob, json, os, subprocess, sys
 
-GEMMS = ("gemm_bf16_nt_v6_kernel<1>", "gemm_bf16_nt_v7_kernel<1>")
+GEMMS = ("gemm_bf16_nt_v6_kernel<1>", "gemm_bf16_nt_v7_kernel<1")      # (v7 carries a second template argument: <1, false> / <1, true>)
 
 
 def commit():

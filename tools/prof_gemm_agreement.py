@@ -8,7 +8,7 @@ rows = []
 for f in glob.glob(path + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "gemm_bf16_nt_v6_kernel<1>" in k or "gemm_bf16_nt_v7_kernel<1>" in k:
+        if "gemm_bf16_nt_v6_kernel<1>" in k or "gemm_bf16_nt_v7_kernel<1" in k:
             rows.append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
 rows.sort()
 d = [x[1] for x in rows]
