@@ -479,194 +479,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_dh64_s257_kernel(const AttnPa
     s257_unit<NQW>(p, sK, sV, scr, b, h, NQW == 2 ? 2 * wave : 8 * half + wave, half == 0, tid, wave);
 }
 
-// ---- S = 257, PERSISTENT: one 1024-thread workgroup per CU walks its (b, h) (B H = 768 on 256 CUs: three each) -------------------------
-// The one-workgroup-per-(b, h) kernel above keeps two workgroups on a CU, so 768 (b, h) are a round of 512 and a round of 256 that
-// leaves every second slot idle and the lone workgroup latency-bound (PMC: 89 % of the issue slots taken while two share a CU, 44 %
-// afterwards), and every workgroup pays its own staging latency.  Here a CU's 16 waves (four per SIMD throughout) take ONE patch-query
-// subtile each, K / V are double-buffered in LDS (2 x 72 KB): the next (b, h)'s rows and Q fragments are issued right after the barrier
-// that opens the current one and land under its arithmetic.  vmcnt is in order; per (b, h) a wave issues 10 operations (2 LDS-DMA
-// pieces of rows 256..287, 4 Q-fragment loads by inline asm, 4 pieces of rows 0..255) and then 4 output stores (wave 15: the class row
-// too), so "the current (b, h) has landed" is vmcnt(4) — only the previous one's stores may still fly — and vmcnt(0) for the first.
-constexpr int P16_WAVES = 16;
-constexpr int LDS_P16 = 2 * (2 * CR257 * 128) + P16_WAVES * SCR_LD * 4;
-
-__global__ __launch_bounds__(1024, 4) void attn_fwd_dh64_s257_p16_kernel(const AttnParams p, const int n_items) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* scr = (float*)(smem + 2 * (2 * CR257 * 128));
-    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, kq = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bf16_t* zero = (const bf16_t*)g_zero16_attn;
-    const float c = p.scale_log2e;
-    const int tr_q = fr >> 2, tr_p = fr & 3;
-
-    auto ld16 = [&](bf16x8& dst, const bf16_t* src) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory"); };
-    // LDS-DMA by inline asm (M0 = the wave-uniform LDS byte address, set in the same statement; cdna guide §5.7): issued through the
-    // builtin, hipcc knows an LDS write is pending on the vector-memory counter and put s_waitcnt vmcnt(0) in front of the transposed V
-    // reads INSIDE the key-block loop (they may alias it) — every (b, h) then waited for the next one's prefetch.  The hand-placed counted
-    // waits and the barriers of this kernel are what orders these writes against the reads.
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    auto glds16_asm = [&](const bf16_t* gsrc, unsigned lds_dst) {
-        unsigned keep;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
-    };
-    // the 10 loads of one (b, h) into buffer `buf` / the fragment registers given
-    auto issue = [&](int item, int buf, bf16x8 (&qf)[2], bf16x8 (&qc)[2]) {
-        const int b = item / p.H, h = item - b * p.H;
-        const size_t row0 = (size_t)b * S257;
-        const unsigned sK = lds0 + buf * (2 * CR257 * 128), sV = sK + CR257 * 128;
-        auto pass = [&](int i, int wsrc) {          // rows 128 i + 8 wsrc + lane / 8; rows past 256 are copies of row 256 (never used as keys)
-            const int row = min(i * 128 + wsrc * 8 + (lane >> 3), S257 - 1), lrow = i * 128 + wsrc * 8 + (lane >> 3);
-            const int ch = (lane & 7) ^ (lrow & 7);
-            glds16_asm(p.k + (row0 + row) * p.ldk + h * 64 + ch * 8, sK + (i * 1024 + wsrc * 64) * 16);
-            glds16_asm(p.v + (row0 + row) * p.ldv + h * 64 + ch * 8, sV + (i * 1024 + wsrc * 64) * 16);
-        };
-        pass(2, wave & 3);
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            ld16(qf[s2], p.q + (row0 + 1 + wave * 16 + fr) * p.ldq + h * 64 + s2 * 32 + kq * 8);
-            ld16(qc[s2], fr == 0 ? p.q + row0 * p.ldq + h * 64 + s2 * 32 + kq * 8 : zero);
-        }
-        pass(0, wave);
-        pass(1, wave);
-    };
-
-    bf16x8 qf[2], qc[2], qfn[2], qcn[2];
-    int item = blockIdx.x;
-    if (item >= n_items) return;
-    issue(item, 0, qf, qc);
-    for (int j = 0; item < n_items; ++j, item += gridDim.x) {
-        const int b = item / p.H, h = item - b * p.H;
-        const size_t row0 = (size_t)b * S257;
-        const char* sK = smem + (j & 1) * (2 * CR257 * 128);
-        const char* sV = sK + CR257 * 128;
-        // this (b, h) has landed in every wave (only the previous one's output stores may still be in flight)
-        if (j == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qc[0]), "+v"(qc[1])::"memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        __builtin_amdgcn_s_barrier();               // ... and every wave has left the other buffer (it finished the previous (b, h))
-        __builtin_amdgcn_sched_barrier(0);
-        const bool more = item + (int)gridDim.x < n_items;
-        if (more) issue(item + gridDim.x, (j + 1) & 1, qfn, qcn);
-
-        auto k_frag = [&](int krow, bf16x8& k0, bf16x8& k1) {
-            const char* base = sK + krow * 128;
-            k0 = *(const bf16x8*)(base + (((0 + kq) ^ (krow & 7)) << 4));
-            k1 = *(const bf16x8*)(base + (((4 + kq) ^ (krow & 7)) << 4));
-        };
-        // ---- patch subtile of this wave: online softmax from key 256, then four full key blocks -----------------------------------------
-        WaveState<1> w;
-        w.qf[0][0] = qf[0];
-        w.qf[0][1] = qf[1];
-        {
-            bf16x8 k0, k1;
-            k_frag(256 + fr, k0, k1);
-            f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, w.qf[0][0], a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, w.qf[0][1], a, 0, 0, 0);
-            w.m_run[0] = colmax4(kq == 0 ? a[0] : -INFINITY);
-            w.l_run[0] = kq == 0 ? 1.0f : 0.0f;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const bf16x4 vq = *(const bf16x4*)(sV + 256 * 128 + dt * 32 + kq * 8);
-                const uint2 vv = __builtin_bit_cast(uint2, vq);
-                w.o[0][dt] = (f32x4){__uint_as_float(vv.x << 16), __uint_as_float(vv.x & 0xffff0000u),
-                                     __uint_as_float(vv.y << 16), __uint_as_float(vv.y & 0xffff0000u)};
-            }
-        }
-#pragma unroll 1
-        for (int kb = 0; kb < 4; ++kb) key_block<1, false, true>(w, sK, sV, kb, 64, c, fr, kq);
-        {
-            float l = w.l_run[0];
-            l += __shfl_xor(l, 16, 64);
-            l += __shfl_xor(l, 32, 64);
-            const float inv = 1.0f / l;
-            const int qi = 1 + wave * 16 + fr;
-            if (p.lse && kq == 0) p.lse[((size_t)b * p.H + h) * S257 + qi] = w.m_run[0] * c + __log2f(l);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                uint2 v;
-                v.x = pack_bf2(w.o[0][dt][0] * inv, w.o[0][dt][1] * inv);
-                v.y = pack_bf2(w.o[0][dt][2] * inv, w.o[0][dt][3] * inv);
-                *(uint2*)(p.o + (row0 + qi) * p.ldo + h * 64 + dt * 16 + kq * 4) = v;
-            }
-        }
-        // ---- class query: key tile `wave` (keys 16 wave ..); wave 0 also key 256 ---------------------------------------------------------
-        {
-            f32x4 st0, st1 = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-            bf16x8 k0, k1;
-            k_frag(wave * 16 + fr, k0, k1);
-            st0 = (f32x4){0.f, 0.f, 0.f, 0.f};
-            st0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qc[0], st0, 0, 0, 0);
-            st0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qc[1], st0, 0, 0, 0);
-            if (wave == 0) {
-                k_frag(256 + fr, k0, k1);
-                f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qc[0], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qc[1], a, 0, 0, 0);
-                st1 = (f32x4){kq == 0 ? a[0] : -INFINITY, -INFINITY, -INFINITY, -INFINITY};
-            }
-            float mx = fmaxf(fmaxf(fmaxf(st0[0], st0[1]), fmaxf(st0[2], st0[3])), fmaxf(fmaxf(st1[0], st1[1]), fmaxf(st1[2], st1[3])));
-            mx = colmax4(mx);
-            const float mc = mx * c;
-            float ls = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                st0[r] = __builtin_amdgcn_exp2f(fmaf(st0[r], c, -mc));
-                st1[r] = __builtin_amdgcn_exp2f(fmaf(st1[r], c, -mc));        // exp2(-inf) = 0
-                ls += st0[r] + st1[r];
-            }
-            ls += __shfl_xor(ls, 16, 64);
-            ls += __shfl_xor(ls, 32, 64);
-            union { bf16x8 v; uint32_t u[4]; } pk;
-            pk.u[0] = pack_bf2(st0[0], st0[1]);
-            pk.u[1] = pack_bf2(st0[2], st0[3]);
-            pk.u[2] = pack_bf2(st1[0], st1[1]);
-            pk.u[3] = pack_bf2(st1[2], st1[3]);
-            const int key0 = wave * 16 + kq * 4 + tr_q, key1 = 256 + kq * 4 + tr_q;       // (waves != 0: P of the second half is zero)
-            f32x4 oc[4];
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const int chunk = dt * 2 + (tr_p >> 1), off = (tr_p & 1) * 8;
-                const bf16x4 v0 = lds_tr16(sV + key0 * 128 + ((chunk ^ (key0 & 7)) << 4) + off);
-                const bf16x4 v1 = lds_tr16(sV + key1 * 128 + ((chunk ^ (key1 & 7)) << 4) + off);
-                const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-                oc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pk.v, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            }
-            if (fr == 0) {
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) *(f32x4*)(scr + wave * SCR_LD + dt * 16 + kq * 4) = oc[dt];
-                if (kq == 0) { scr[wave * SCR_LD + 64] = mx; scr[wave * SCR_LD + 65] = ls; }
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);         // lgkmcnt(0): the scratch writes above
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (wave == P16_WAVES - 1) {                // combine the 16 partials: lane = output feature d
-            float M = -INFINITY;
-#pragma unroll
-            for (int i = 0; i < P16_WAVES; ++i) M = fmaxf(M, scr[i * SCR_LD + 64]);
-            float L = 0.f, O = 0.f;
-#pragma unroll
-            for (int i = 0; i < P16_WAVES; ++i) {
-                const float f = __builtin_amdgcn_exp2f((scr[i * SCR_LD + 64] - M) * c);
-                L = fmaf(scr[i * SCR_LD + 65], f, L);
-                O = fmaf(scr[i * SCR_LD + lane], f, O);
-            }
-            typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
-            const bf2_t ob = __builtin_convertvector((f32x2){O / L, 0.f}, bf2_t);
-            p.o[row0 * p.ldo + h * 64 + lane] = __builtin_bit_cast(uint32_t, ob) & 0xffffu;
-            if (p.lse && lane == 0) p.lse[((size_t)b * p.H + h) * S257] = M * c + __log2f(L);
-        }
-        if (more) {
-            // The next (b, h)'s Q fragments were issued at the top of this iteration: wait for them HERE, before the loop's back edge — as a
-            // loop-carried value the compiler may copy an asm load's destination at the back edge, and a copy ahead of the wait would read
-            // registers the load has not written yet.  Younger than those four loads: 4 LDS-DMA pieces + this (b, h)'s >= 4 stores.
-            asm volatile("s_waitcnt vmcnt(8)" : "+v"(qfn[0]), "+v"(qfn[1]), "+v"(qcn[0]), "+v"(qcn[1])::"memory");
-            qf[0] = qfn[0]; qf[1] = qfn[1]; qc[0] = qcn[0]; qc[1] = qcn[1];
-        }
-    }
-}
+// Measured and removed (round 3, git history: "attention: persistent 16-wave S=257 kernel"): ONE 1024-thread workgroup per CU walking its
+// three (b, h) with K / V double-buffered and one subtile per wave — 37.8-39.1 us against 32.6 for the kernels above.  A wave's chain
+// (init, four key blocks, class-query share, two barriers) is latency-bound; two subtiles per wave give it two independent chains to
+// interleave, one subtile per wave does not, and sixteen such waves per CU do not make up for it.
 
 }  // namespace
 
@@ -691,23 +507,13 @@ static int attn_fwd_launch(const void* q, const void* k, const void* v, void* o,
         // resident slots: 2 workgroups per CU (LDS).  Whole rounds of (b, h) as <2>; a remainder of at most half a round as <1> halves
         // (MEDP_ATTN_S257_BALANCE=1 or medp_dbg_attn_s257_slots: the half-unit arrangement, kept for A/B runs and its test)
         static const int dev_slots = [] { int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); return 2 * cus; }();
-        const int slots = g_s257_slots_override > 0 ? g_s257_slots_override : dev_slots;      // (reached with MEDP_ATTN_S257_PERSIST=0 or a positive override)
+        const int slots = g_s257_slots_override > 0 ? g_s257_slots_override : dev_slots;
         // Measured (B 64, H 12: 768 (b, h) on 512 slots): whole units only 32.2 us, whole + half units 37.8 us — a (b, h)'s cost is its 99 KB of
         // loads, not its 16 subtiles of arithmetic, and a half unit loads all of K / V for half the queries.  Default: whole units.
         static const int bal = [] { const char* e = getenv("MEDP_ATTN_S257_BALANCE"); return e ? atoi(e) : 0; }();
-        static const int persist = [] { const char* e = getenv("MEDP_ATTN_S257_PERSIST"); return e ? atoi(e) : 1; }();
-        if (persist && g_s257_slots_override <= 0) {     // (override < 0, tests: the persistent kernel on that many workgroups)
-            MEDP_ONCE_PER_DEVICE({
-                hipFuncSetAttribute((const void*)attn_fwd_dh64_s257_p16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_P16);
-            });
-            const int n_items = B * H;
-            const int wgs = g_s257_slots_override < 0 ? -g_s257_slots_override : dev_slots / 2;
-            attn_fwd_dh64_s257_p16_kernel<<<min(n_items, wgs), 1024, LDS_P16, (hipStream_t)stream>>>(p, n_items);
-            MEDP_LAUNCH_CHECK("medp_attn_fwd_dh64(S=257, persistent)");
-            return 0;
-        }
         const int n = B * H, rem = n % slots;
-        const int n_half = (bal && n > slots && rem > 0 && 2 * rem <= slots) ? rem : 0, n_whole = n - n_half;
+        const bool halves = bal || g_s257_slots_override > 0;        // (the test hook plans halves on its pretended slots)
+        const int n_half = (halves && n > slots && rem > 0 && 2 * rem <= slots) ? rem : 0, n_whole = n - n_half;
         attn_fwd_dh64_s257_kernel<2><<<n_whole, 512, LDS_257, (hipStream_t)stream>>>(p, 0);
         if (n_half) attn_fwd_dh64_s257_kernel<1><<<2 * n_half, 512, LDS_257, (hipStream_t)stream>>>(p, n_whole);
         MEDP_LAUNCH_CHECK("medp_attn_fwd_dh64(S=257)");
@@ -742,6 +548,6 @@ extern "C" int medp_attn_fwd_dh64_lse(const void* q, const void* k, const void* 
 // with (0 = the device's own 2 x CUs), so that the half-unit kernel can be exercised at small B x H.  Returns the previous value.
 extern "C" int medp_dbg_attn_s257_slots(int slots) {
     const int prev = g_s257_slots_override;
-    g_s257_slots_override = slots;          // > 0: the one-workgroup-per-(b, h) kernels planning with that many slots; < 0: the persistent kernel on -slots workgroups
+    g_s257_slots_override = slots > 0 ? slots : 0;
     return prev;
 }

@@ -178,7 +178,7 @@ def test_attn_dh64_forced_rescale():
     assert_close(got, want, 1e-2, 1e-2, "attn_dh64 rescale")
 
 
-@pytest.mark.parametrize("arrangement", ["persistent", "whole_and_half_units"])
+@pytest.mark.parametrize("arrangement", ["whole_units", "whole_and_half_units"])
 @pytest.mark.parametrize("case", ["late_key", "key256", "cls_query", "cls_key", "ramp"])
 def test_attn_dh64_s257_rescale_paths(case, arrangement, request):
     """The S = 257 kernel (one workgroup per (batch, head), online softmax initialised from key 256, deferred rescale, class query
@@ -191,10 +191,9 @@ def test_attn_dh64_s257_rescale_paths(case, arrangement, request):
       ramp     : scores grow by a few units per block: growth both below and above the defer threshold"""
     B, S, H = 2, 257, 3
     D = H * 64
-    # "persistent" (the default kernel): 6 (b, h) on TWO 1024-thread workgroups — three each, so the double-buffered K / V hand-over and
-    # both counted waits run; "whole_and_half_units": the one-workgroup-per-(b, h) kernels on a pretended 4 resident slots = 4 whole
-    # units (two subtiles per wave) + 2 x 2 half units (one subtile per wave).  Every kernel sees every forced path.
-    prev = lib().medp_dbg_attn_s257_slots(-2 if arrangement == "persistent" else 4)
+    # "whole_units" (the default arrangement): one workgroup per (b, h), two subtiles per wave; "whole_and_half_units" (MEDP_ATTN_S257_BALANCE=1,
+    # measured slower): on a pretended 4 resident slots the 6 (b, h) run as 4 whole units + 2 x 2 half units (one subtile per wave).
+    prev = lib().medp_dbg_attn_s257_slots(4 if arrangement == "whole_and_half_units" else 0)
     request.addfinalizer(lambda: lib().medp_dbg_attn_s257_slots(prev))
     qkv = bf_round(rnd(B * S, 3 * D, seed=23) * 0.5)
     x = qkv.view(B, S, 3, H, 64)
