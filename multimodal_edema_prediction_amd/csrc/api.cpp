@@ -14,7 +14,7 @@ void medp_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* medp_last_error(void) { return g_err; }
-extern "C" int medp_version(void) { return 1; }
+extern "C" int medp_version(void) { return 2; }      // 2: MedpVitLayer carries the LayerNorm-fold operands (round 3)
 extern "C" const char* medp_arch(void) { return "gfx950"; }
 
 // ---- RNG epoch (see common.h) and a one-word device counter ------------------------------------------------------------
