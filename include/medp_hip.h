@@ -90,15 +90,18 @@ int medp_attn_fwd_dh64(const void* q, const void* k, const void* v, void* o, int
  * Returns -2 (nothing launched) for shapes it is not built for: the caller then uses medp_attn_small_fwd. */
 int medp_attn_dh16_fwd(const float* qkv, int ld, void* o_bf16, int ldo, int B, int N, int H, int dh, float scale, void* stream);
 /* The same attention in TRAINING form (the student-KD step: dropout on the probabilities, gradients to q, k, v; autograd of
- * duett/duett.py:95-105): forward writes fp32 o [B*N][ldo] and the rows' log2-sum-exp lse [B*H*N]; backward writes dQ | dK | dV into
+ * duett/duett.py:95-105): forward writes o [B*N][ldo] and the rows' log2-sum-exp lse [B*H*N]; backward writes dQ | dK | dV into
  * the column blocks of dqkv [B*N][lddqkv] (delta_ws: B*H*N floats of scratch).  Three MFMA kernels, a wave per 16-row tile, no LDS,
  * nothing added into memory (bitwise reproducible); same dropout stream as medp_attn_small_*.  Both return -2 (nothing launched)
  * for unsupported shapes. */
-int medp_attn_dh16_train_fwd(const float* qkv, int ld, float* o, int ldo, float* lse, int B, int N, int H, int dh, float scale,
+/* io_bf16 = 0: qkv, dout fp32 in, o, dqkv fp32 out (rounded to bf16 MFMA operands inside).  io_bf16 = 1: all four are bf16 — the
+ * 16-bit hand-over between the projection GEMMs and the attention of a training step; the same operand bits, so the same results. */
+int medp_attn_dh16_train_supported(int B, int N, int H, int dh, int ld, int ldo);   /* 1: the shapes these kernels take (16-byte aligned buffers assumed) */
+int medp_attn_dh16_train_fwd(const void* qkv, int ld, void* o, int ldo, float* lse, int io_bf16, int B, int N, int H, int dh, float scale,
                              float dropout_p, unsigned seed, unsigned stream_id, void* stream);
-int medp_attn_dh16_train_bwd(const float* dout, int lddo, const float* qkv, int ld, const float* lse, float* delta_ws, float* dqkv,
-                             int lddqkv, int B, int N, int H, int dh, float scale, float dropout_p, unsigned seed, unsigned stream_id,
-                             void* stream);
+int medp_attn_dh16_train_bwd(const void* dout, int lddo, const void* qkv, int ld, const float* lse, float* delta_ws, void* dqkv,
+                             int lddqkv, int io_bf16, int B, int N, int H, int dh, float scale, float dropout_p, unsigned seed,
+                             unsigned stream_id, void* stream);
 /* Training form (--unfreeze_cxr, run.py:184-187): the same forward that also writes lse[B,H,S], the log2-domain logsumexp of the
  * scaled scores, and the flash backward that consumes it.  prep: dsum[b,h,s] = <dout, o> and the bf16 copy of dout.
  * bwd: dq/dk/dv fp32 with row stride ldd (e.g. the three column blocks of one [B*S, 3*H*64] buffer); q/k/v/dout_bf16 bf16. */
@@ -139,6 +142,19 @@ int medp_scalenorm_bwd(const float* dy, int lddy, const float* x, int ldx, const
 /* ---- layout / pointwise ------------------------------------------------------------------------------ */
 int medp_cast_f32_bf16(const float* x, int ldx, void* y, int ldy, int rows, int cols, void* stream);
 int medp_transpose_to_bf16(const void* x, int x_is_bf16, int ldx, void* y, int ldy, int rows, int cols, void* stream);
+/* The bf16 GEMM operands of MANY fp32 weight matrices in one launch (the per-step casts of a training step's trainable weights: each
+ * nn.Linear of the reference needs W as bf16 [N,K] for y = x W^T and W^T as bf16 [K, Npad8] for dX = dY W).  Job: src fp32 [rows, ld_src];
+ * dst_plain bf16 [rows, ld_plain] and / or dst_t bf16 [cols, ld_t] (either may be NULL; pad columns of dst_t are the caller's zeros).
+ * Block b handles the 64x64 tile dev_block_tile[b] (row-major over ceil(rows/64) x ceil(cols/64)) of job dev_block_job[b].
+ * Same rounding as medp_cast_f32_bf16 / medp_transpose_to_bf16. */
+typedef struct {
+    const void* src;
+    void* dst_plain;
+    void* dst_t;
+    int rows, cols, ld_src, ld_plain, ld_t, reserved_;
+} MedpOperandJob;
+int medp_weight_operands_multi(const MedpOperandJob* dev_jobs, const int* dev_block_job, const int* dev_block_tile, int n_blocks,
+                               void* stream);
 int medp_gelu_bwd(const float* dy, const float* pre, float* dx, long long n, void* stream);
 /* bf16 forms (trainable CXR encoder, fused blocks): out = gelu(pre); dx = dy * gelu'(pre); all three bf16, n % 8 == 0 */
 int medp_gelu_bf16_fwd(const void* pre, void* out, long long n, void* stream);
@@ -273,6 +289,12 @@ int medp_duett_encode(const MedpDuettWeights* host_w, const float* xs_static, co
 int medp_gelu_dropout_fwd(const float* x, float* y, long long n, float p, unsigned seed, unsigned stream_id, void* stream);
 int medp_gelu_dropout_bwd(const float* dy, const float* x, float* dx, long long n, float p, unsigned seed, unsigned stream_id,
                           void* stream);
+/* 16-bit hand-over forms for a fused feed-forward node (ScaleNorm -> Linear -> GELU -> Dropout -> Linear of x_transformers' FeedForward):
+ * the forward writes the next Linear's bf16 operand directly; the backward writes dx in fp32 (bias gradient) AND its bf16 copy (operand of
+ * the previous Linear's gradient GEMMs).  Same rounding as medp_cast_f32_bf16 on the fp32 result. */
+int medp_gelu_dropout_fwd_bf16(const float* x, void* y_bf16, long long n, float p, unsigned seed, unsigned stream_id, void* stream);
+int medp_gelu_dropout_bwd_bf16(const float* dy, const float* x, float* dx, void* dx_bf16, long long n, float p, unsigned seed,
+                               unsigned stream_id, void* stream);
 /* out = residual + dropout(y) (residual may be NULL; backward = same call on the incoming gradient with residual NULL) */
 int medp_dropout_add(const float* y, const float* residual, float* out, long long n, float p, unsigned seed, unsigned stream_id,
                      void* stream);

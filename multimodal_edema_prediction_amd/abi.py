@@ -50,6 +50,11 @@ class MedpAdamTensor(ctypes.Structure):
     _fields_ = [("param", P), ("grad", P), ("exp_avg", P), ("exp_avg_sq", P), ("numel", LL), ("lr", F), ("weight_decay", F)]
 
 
+class MedpOperandJob(ctypes.Structure):
+    _fields_ = [("src", P), ("dst_plain", P), ("dst_t", P), ("rows", I), ("cols", I), ("ld_src", I), ("ld_plain", I), ("ld_t", I),
+                ("reserved_", I)]
+
+
 # name -> (restype, argtypes); must list every function declared in include/medp_hip.h (tests/test_abi.py checks)
 SIGNATURES = {
     "medp_last_error": (c_char_p, []),
@@ -67,8 +72,9 @@ SIGNATURES = {
     "medp_gemm_profile_collect": (I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_longlong), ctypes.POINTER(ctypes.c_double)]),
     "medp_attn_fwd_dh64": (I, [P, P, P, P, I, I, I, I, I, I, I, F, P]),
     "medp_attn_dh16_fwd": (I, [P, I, P, I, I, I, I, I, F, P]),
-    "medp_attn_dh16_train_fwd": (I, [P, I, P, I, P, I, I, I, I, F, F, U, U, P]),
-    "medp_attn_dh16_train_bwd": (I, [P, I, P, I, P, P, P, I, I, I, I, I, F, F, U, U, P]),
+    "medp_attn_dh16_train_supported": (I, [I, I, I, I, I, I]),
+    "medp_attn_dh16_train_fwd": (I, [P, I, P, I, P, I, I, I, I, I, F, F, U, U, P]),
+    "medp_attn_dh16_train_bwd": (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, F, F, U, U, P]),
     "medp_attn_fwd_dh64_lse": (I, [P, P, P, P, P, I, I, I, I, I, I, I, F, P]),
     "medp_attn_bwd_dh64_prep": (I, [P, I, P, I, P, I, P, I, I, I, P]),
     "medp_attn_bwd_dh64": (I, [P, P, P, I, P, I, P, P, P, P, P, I, I, I, I, F, P]),
@@ -82,6 +88,7 @@ SIGNATURES = {
     "medp_scalenorm_bwd": (I, [P, I, P, I, P, P, P, I, I, P, P, I, I, P]),
     "medp_cast_f32_bf16": (I, [P, I, P, I, I, I, P]),
     "medp_transpose_to_bf16": (I, [P, I, I, P, I, I, I, P]),
+    "medp_weight_operands_multi": (I, [P, P, P, I, P]),
     "medp_gelu_bwd": (I, [P, P, P, LL, P]),
     "medp_gelu_bf16_fwd": (I, [P, P, LL, P]),
     "medp_gelu_bf16_bwd": (I, [P, P, P, LL, P]),
@@ -100,6 +107,8 @@ SIGNATURES = {
     "medp_duett_encode": (I, [ctypes.POINTER(MedpDuettWeights), P, P, P, I, I, P, P, P, P, SZ, P]),
     "medp_gelu_dropout_fwd": (I, [P, P, LL, F, U, U, P]),
     "medp_gelu_dropout_bwd": (I, [P, P, P, LL, F, U, U, P]),
+    "medp_gelu_dropout_fwd_bf16": (I, [P, P, LL, F, U, U, P]),
+    "medp_gelu_dropout_bwd_bf16": (I, [P, P, P, P, LL, F, U, U, P]),
     "medp_dropout_add": (I, [P, P, P, LL, F, U, U, P]),
     "medp_rowdot_fwd": (I, [P, I, P, P, P, I, I, P]),
     "medp_rowdot_bwd": (I, [P, P, I, P, P, P, P, I, I, P]),

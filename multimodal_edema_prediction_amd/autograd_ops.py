@@ -36,10 +36,60 @@ def _cached(t: torch.Tensor, kind: str, make):
     return val
 
 
+def _seed(t: torch.Tensor, kind: str, val: torch.Tensor) -> None:
+    """Put `val` into the cache as the `kind` operand of `t` at its current version (WeightOperandPool.refresh)."""
+    base = t._base if t._base is not None else t
+    slot = _W_CACHE.get(base)
+    if slot is None:
+        slot = {}
+        _W_CACHE[base] = slot
+    slot[(t.storage_offset(), tuple(t.shape), tuple(t.stride()), kind)] = (t._version, val)
+
+
+def _cached_group(ts, kind: str, make):
+    """`_cached` for an operand made of SEVERAL tensors (to_q | to_k | to_v stacked by rows): filed under the first one, valid while
+    every member is the same object at the same version."""
+    slot = _W_CACHE.get(ts[0])
+    if slot is None:
+        slot = {}
+        _W_CACHE[ts[0]] = slot
+    vers = tuple(t._version for t in ts)
+    hit = slot.get(kind)
+    if hit is not None and hit[0] == vers and len(hit[2]) == len(ts) - 1 and all(a is b for a, b in zip(hit[2], ts[1:])):
+        return hit[1]
+    val = make([t.detach() for t in ts])
+    slot[kind] = (vers, val, tuple(ts[1:]))
+    return val
+
+
+# while graph_step records a warm-up step: every (weights, kind) a trainable weight's operand was asked for, in order
+_OPERAND_LOG = None
+
+
+def _log_operand(ws, kind):
+    if _OPERAND_LOG is not None and all(w.requires_grad and w.is_leaf and w.dim() == 2 and w.is_contiguous() for w in ws):
+        _OPERAND_LOG.append((tuple(ws), kind))
+
+
+class record_operands:
+    """with record_operands() as log: ... one training step ...  ->  log = [((weights...), "bf16" | "t_bf16"), ...] for WeightOperandPool"""
+
+    def __enter__(self):
+        global _OPERAND_LOG
+        self._prev, _OPERAND_LOG = _OPERAND_LOG, []
+        return _OPERAND_LOG
+
+    def __exit__(self, *exc):
+        global _OPERAND_LOG
+        _OPERAND_LOG = self._prev
+        return False
+
+
 def weight_bf16(w: torch.Tensor) -> torch.Tensor:
     """The weight as a GEMM operand: a cached bf16 copy; in fp32 mode (functional.set_precision) the fp32 weight itself."""
     if Fn.precision() == "fp32":
         return w.detach().contiguous()
+    _log_operand((w,), "bf16")
     return _cached(w, "bf16", lambda t: Fn.operand(t.contiguous()) if t.shape[-1] % 4 == 0 else t.to(BF16))
 
 
@@ -47,7 +97,91 @@ def weight_t_bf16(w: torch.Tensor) -> torch.Tensor:
     """[N,K] fp32 -> [K, Npad8] bf16 (operand of dX = dY · W)."""
     if Fn.precision() == "fp32":
         return _cached(w, "t_f32", lambda t: Fn.operand_t(t.contiguous()))
+    _log_operand((w,), "t_bf16")
     return _cached(w, "t_bf16", lambda t: Fn.operand_t(t.contiguous()))
+
+
+def weights_cat_bf16(ws) -> torch.Tensor:
+    """[W0; W1; ...] (rows stacked) as ONE GEMM operand: bf16 [sum N_i, K]; fp32 mode: the fp32 stack."""
+    if Fn.precision() == "fp32":
+        return torch.cat([w.detach() for w in ws], 0)
+    _log_operand(tuple(ws), "bf16")
+    return _cached_group(tuple(ws), "cat_bf16", lambda ts: Fn.operand(torch.cat(ts, 0)) if ts[0].shape[-1] % 4 == 0 else torch.cat(ts, 0).to(BF16))
+
+
+def weights_cat_t_bf16(ws) -> torch.Tensor:
+    """[W0; W1; ...]^T: [K, pad8(sum N_i)] bf16 (fp32 in fp32 mode), the operand of dX = dY [W0; W1; ...]."""
+    if Fn.precision() == "fp32":
+        return Fn.operand_t(torch.cat([w.detach() for w in ws], 0))
+    _log_operand(tuple(ws), "t_bf16")
+    return _cached_group(tuple(ws), "cat_t_bf16", lambda ts: Fn.operand_t(torch.cat(ts, 0)))
+
+
+class WeightOperandPool:
+    """The bf16 GEMM operands of a training step's trainable weights, all written by ONE launch (`medp_weight_operands_multi`).
+    A step asks `weight_bf16` / `weight_t_bf16` / `weights_cat_*` once per nn.Linear and direction; after an optimiser update every
+    one of them is a cast or transpose launch of its own (48 + 18 per student step, profiles/r03_kerneltrace_bench_student.txt).
+    Built from the log of a recorded warm-up step; `refresh()` converts every weight into its preallocated buffers and files those
+    in the operand cache at the weights' current versions, so the step that follows finds them there (same rounding: bit-identical
+    operands).  A weight the pool does not know, or a step that runs without `refresh()`, falls back to the per-tensor kernels."""
+
+    def __init__(self, log, device):
+        from .abi import MedpOperandJob
+        groups = {}                                           # id-tuple -> [weights, want_plain, want_t]
+        for ws, kind in log:
+            g = groups.setdefault(tuple(id(w) for w in ws), [ws, False, False])
+            g[1 if kind == "bf16" else 2] = True
+        self._groups = []
+        jobs, blk_job, blk_tile = [], [], []
+        for ws, want_plain, want_t in groups.values():
+            K = ws[0].shape[1]
+            if any(w.shape[1] != K or w.dtype != F32 or w.device != ws[0].device for w in ws):
+                continue
+            n_all = sum(w.shape[0] for w in ws)
+            plain = torch.empty((n_all, K), dtype=BF16, device=device) if want_plain else None
+            npad = (n_all + 7) // 8 * 8
+            tr = torch.zeros((K, npad), dtype=BF16, device=device) if want_t else None      # pad columns stay zero
+            off = 0
+            for w in ws:
+                n = w.shape[0]
+                jobs.append(MedpOperandJob(w.data_ptr(), plain.data_ptr() + off * K * 2 if want_plain else None,
+                                           tr.data_ptr() + off * 2 if want_t else None, n, K, K, K, npad, 0))
+                tiles = ((n + 63) // 64) * ((K + 63) // 64)
+                blk_job += [len(jobs) - 1] * tiles
+                blk_tile += list(range(tiles))
+                off += n
+            self._groups.append((tuple(ws), plain, tr))
+        self.n_jobs, self.n_blocks = len(jobs), len(blk_job)
+        if jobs:
+            raw = bytes((MedpOperandJob * len(jobs))(*jobs))
+            self._jobs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+            self._blk_job = torch.tensor(blk_job, dtype=torch.int32).to(device)
+            self._blk_tile = torch.tensor(blk_tile, dtype=torch.int32).to(device)
+            self._ptrs = [w.data_ptr() for ws, _, _ in self._groups for w in ws]
+
+    def refresh(self):
+        if not self.n_jobs:
+            return
+        if self._ptrs != [w.data_ptr() for ws, _, _ in self._groups for w in ws]:
+            raise RuntimeError("WeightOperandPool: a pooled weight moved (module.to(...) after the pool was built); build a new pool")
+        check(lib().medp_weight_operands_multi(ptr(self._jobs), ptr(self._blk_job), ptr(self._blk_tile), self.n_blocks, stream()),
+              "weight_operands_multi")
+        for ws, plain, tr in self._groups:
+            if len(ws) == 1:
+                if plain is not None:
+                    _seed(ws[0], "bf16", plain)
+                if tr is not None:
+                    _seed(ws[0], "t_bf16", tr)
+            else:
+                slot = _W_CACHE.get(ws[0])
+                if slot is None:
+                    slot = {}
+                    _W_CACHE[ws[0]] = slot
+                vers = tuple(w._version for w in ws)
+                if plain is not None:
+                    slot["cat_bf16"] = (vers, plain, tuple(ws[1:]))
+                if tr is not None:
+                    slot["cat_t_bf16"] = (vers, tr, tuple(ws[1:]))
 
 
 _SEED_STATE = {"n": 0}
@@ -131,6 +265,50 @@ class LinearFn(torch.autograd.Function):
 
 def linear(x, weight, bias=None, residual=None):
     return LinearFn.apply(x, weight, bias, residual)
+
+
+class LinearCatFn(torch.autograd.Function):
+    """y = x [W0; W1; ...]^T — several bias-free Linears on one input (to_q / to_k / to_v of x_transformers' Attention) as ONE GEMM,
+    without materialising the stacked weight through autograd: `torch.cat` of the three parameters cost a copy kernel, a cast and a
+    transpose of the result per step, and its backward handed autograd non-leaf slices.  Here the stacked operand comes from the
+    operand cache / pool and dW [sum N, K] is returned as its row blocks (contiguous views)."""
+
+    @staticmethod
+    def forward(ctx, x, *ws):
+        if Fn.precision() == "fp32" and x.dtype == BF16:
+            x = x.float()
+        xb = x if x.dtype == BF16 else Fn.operand(x.contiguous())
+        K = ws[0].shape[1]
+        x2 = xb.reshape(-1, K)
+        wb = weights_cat_bf16(ws)
+        y = Fn.gemm(x2, wb, out_dtype=F32, k=K)
+        ctx.save_for_backward(x2, *ws)
+        ctx.x_shape = x.shape
+        return y.view(*x.shape[:-1], wb.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, *ws = ctx.saved_tensors
+        K = ws[0].shape[1]
+        N = sum(w.shape[0] for w in ws)
+        dy2 = dy.reshape(-1, N).contiguous()
+        dyb = Fn.operand(dy2)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = Fn.gemm(dyb, weights_cat_t_bf16(ws), out_dtype=F32, k=N).view(ctx.x_shape)
+        dws = [None] * len(ws)
+        if any(ctx.needs_input_grad[1:]):
+            if N % 8 == 0 and K % 8 == 0 and x2.stride(0) % 8 == 0:
+                dw = Fn.gemm_tn(dyb, x2)
+            else:
+                dyt, xt = Fn.operand_t(dy2), Fn.operand_t(x2)
+                dw = Fn.gemm(dyt, xt, out_dtype=F32, k=dyt.shape[1])
+            dws = list(dw.split([w.shape[0] for w in ws], 0))
+        return (dx, *dws)
+
+
+def linear_cat(x, ws):
+    return LinearCatFn.apply(x, *ws)
 
 
 class LinearScaleResidualFn(torch.autograd.Function):

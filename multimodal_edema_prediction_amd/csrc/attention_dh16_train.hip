@@ -21,15 +21,15 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
 
 struct TrainParams {
-    const float* qkv;     // rows [B*N][ld]: q | k | v column blocks of H*dh each
+    const void* qkv;      // rows [B*N][ld]: q | k | v column blocks of H*dh each; fp32, or bf16 in the 16-bit hand-over form (T = bf16_t)
     int ld;
-    float* o;             // forward: fp32 [B*N][ldo]
+    void* o;              // forward: [B*N][ldo], same element type as qkv
     int ldo;
     float* lse;           // [B*H*N] log2-domain log-sum-exp of the scaled scores
-    const float* dout;    // backward: [B*N][lddo]
+    const void* dout;     // backward: [B*N][lddo], same element type as qkv
     int lddo;
     float* delta;         // [B*H*N] sum_j P dP
-    float* dqkv;          // [B*N][lddqkv], same column blocks
+    void* dqkv;           // [B*N][lddqkv], same column blocks, same element type
     int lddqkv;
     int B, N, H, dh;
     float scale_log2e, scale, drop_p, inv_keep;
@@ -45,11 +45,16 @@ __device__ __forceinline__ bf16x4_t pack4(float a, float b, float c, float d) {
 }
 __device__ __forceinline__ bf16x4_t pack4(const f32x4& v) { return pack4(v[0], v[1], v[2], v[3]); }
 
-// row `row` of a [N][ld] block, elements 4 g4 ..+3 (an operand indexed (row | col = lane & 15, k = head dim))
+// row `row` of a [N][ld] block, elements 4 g4 ..+3 (an operand indexed (row | col = lane & 15, k = head dim)).  fp32 storage is rounded to
+// bf16 here; bf16 storage (the hand-over form: the producing GEMM rounded with the same f2bf) is loaded as it is — the same operand bits
 __device__ __forceinline__ bf16x4_t row_frag(const float* base, int ld, int row, int N, int g4, bool dvalid) {
     if (row >= N || !dvalid) return (bf16x4_t){0, 0, 0, 0};
     const float4 x = *(const float4*)(base + (size_t)row * ld + 4 * g4);
     return pack4(x.x, x.y, x.z, x.w);
+}
+__device__ __forceinline__ bf16x4_t row_frag(const bf16_t* base, int ld, int row, int N, int g4, bool dvalid) {
+    if (row >= N || !dvalid) return (bf16x4_t){0, 0, 0, 0};
+    return *(const bf16x4_t*)(base + (size_t)row * ld + 4 * g4);
 }
 // column `col` of rows r0 ..+3 (an operand indexed (row | col = head dim lane & 15, k = token))
 __device__ __forceinline__ bf16x4_t col_frag(const float* base, int ld, int r0, int N, int col, int dh) {
@@ -61,6 +66,19 @@ __device__ __forceinline__ bf16x4_t col_frag(const float* base, int ld, int r0, 
     }
     return pack4(v[0], v[1], v[2], v[3]);
 }
+__device__ __forceinline__ bf16x4_t col_frag(const bf16_t* base, int ld, int r0, int N, int col, int dh) {
+    bf16x4_t v = {0, 0, 0, 0};
+    if (col < dh) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (r0 + i < N) v[i] = (short)base[(size_t)(r0 + i) * ld + col];
+    }
+    return v;
+}
+__device__ __forceinline__ void store4(float* dst, float a, float b, float c, float d) { *(float4*)dst = make_float4(a, b, c, d); }
+__device__ __forceinline__ void store4(bf16_t* dst, float a, float b, float c, float d) { *(bf16x4_t*)dst = pack4(a, b, c, d); }
+__device__ __forceinline__ void store1(float* dst, float a) { *dst = a; }
+__device__ __forceinline__ void store1(bf16_t* dst, float a) { *dst = f2bf(a); }
 
 __device__ __forceinline__ float keep_scale(const TrainParams& p, uint32_t seed, int bh, int q, int key) {
     return dropout_scale(seed, p.stream_id, ((uint32_t)bh * p.N + q) * p.N + key, p.drop_p, p.inv_keep);
@@ -68,14 +86,14 @@ __device__ __forceinline__ float keep_scale(const TrainParams& p, uint32_t seed,
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0)
 
-template <int NT>
+template <int NT, typename T>
 __global__ __launch_bounds__(256) void dh16_train_fwd_kernel(const TrainParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int qt = blockIdx.x * 4 + wave;
     if (qt * 16 >= p.N) return;
     const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
     const int c16 = lane & 15, g4 = lane >> 4, D = p.H * p.dh;
-    const float* base = p.qkv + (size_t)b * p.N * p.ld + h * p.dh;
+    const T* base = (const T*)p.qkv + (size_t)b * p.N * p.ld + h * p.dh;
     const bool dvalid = 4 * g4 < p.dh;
     const int q = qt * 16 + c16;
     const uint32_t seed = p.drop_p > 0.f ? medp_mix_epoch(p.seed, p.epoch) : 0u;
@@ -114,20 +132,20 @@ __global__ __launch_bounds__(256) void dh16_train_fwd_kernel(const TrainParams p
         if (g4 == 0) p.lse[(size_t)bh * p.N + q] = mc + __log2f(sum);
         if (dvalid) {
             const float inv = 1.0f / sum;
-            *(float4*)(p.o + ((size_t)b * p.N + q) * p.ldo + h * p.dh + 4 * g4) = make_float4(ot[0] * inv, ot[1] * inv, ot[2] * inv, ot[3] * inv);
+            store4((T*)p.o + ((size_t)b * p.N + q) * p.ldo + h * p.dh + 4 * g4, ot[0] * inv, ot[1] * inv, ot[2] * inv, ot[3] * inv);
         }
     }
 }
 
-template <int NT>
+template <int NT, typename T>
 __global__ __launch_bounds__(256) void dh16_train_bwd_dq_kernel(const TrainParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int qt = blockIdx.x * 4 + wave;
     if (qt * 16 >= p.N) return;
     const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
     const int c16 = lane & 15, g4 = lane >> 4, D = p.H * p.dh;
-    const float* base = p.qkv + (size_t)b * p.N * p.ld + h * p.dh;
-    const float* dob = p.dout + (size_t)b * p.N * p.lddo + h * p.dh;
+    const T* base = (const T*)p.qkv + (size_t)b * p.N * p.ld + h * p.dh;
+    const T* dob = (const T*)p.dout + (size_t)b * p.N * p.lddo + h * p.dh;
     const bool dvalid = 4 * g4 < p.dh;
     const int q = qt * 16 + c16;
     const uint32_t seed = p.drop_p > 0.f ? medp_mix_epoch(p.seed, p.epoch) : 0u;
@@ -160,19 +178,19 @@ __global__ __launch_bounds__(256) void dh16_train_bwd_dq_kernel(const TrainParam
     }
     if (q < p.N) {
         if (g4 == 0) p.delta[(size_t)bh * p.N + q] = delta;
-        if (dvalid) *(float4*)(p.dqkv + ((size_t)b * p.N + q) * p.lddqkv + h * p.dh + 4 * g4) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+        if (dvalid) store4((T*)p.dqkv + ((size_t)b * p.N + q) * p.lddqkv + h * p.dh + 4 * g4, dq[0], dq[1], dq[2], dq[3]);
     }
 }
 
-template <int NT>
+template <int NT, typename T>
 __global__ __launch_bounds__(256) void dh16_train_bwd_dkv_kernel(const TrainParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kt = blockIdx.x * 4 + wave;
     if (kt * 16 >= p.N) return;
     const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
     const int c16 = lane & 15, g4 = lane >> 4, D = p.H * p.dh;
-    const float* base = p.qkv + (size_t)b * p.N * p.ld + h * p.dh;
-    const float* dob = p.dout + (size_t)b * p.N * p.lddo + h * p.dh;
+    const T* base = (const T*)p.qkv + (size_t)b * p.N * p.ld + h * p.dh;
+    const T* dob = (const T*)p.dout + (size_t)b * p.N * p.lddo + h * p.dh;
     const bool dvalid = 4 * g4 < p.dh;
     const int key = kt * 16 + c16;
     const uint32_t seed = p.drop_p > 0.f ? medp_mix_epoch(p.seed, p.epoch) : 0u;
@@ -203,9 +221,9 @@ __global__ __launch_bounds__(256) void dh16_train_bwd_dkv_kernel(const TrainPara
         for (int r = 0; r < 4; ++r) {
             const int kk = kt * 16 + 4 * g4 + r;
             if (kk < p.N) {
-                float* row = p.dqkv + ((size_t)b * p.N + kk) * p.lddqkv + h * p.dh + c16;
-                row[D] = dk[r];
-                row[2 * D] = dv[r];
+                T* row = (T*)p.dqkv + ((size_t)b * p.N + kk) * p.lddqkv + h * p.dh + c16;
+                store1(row + D, dk[r]);
+                store1(row + 2 * D, dv[r]);
             }
         }
     }
@@ -216,20 +234,29 @@ bool supported(int B, int N, int H, int dh, int ld, int ld2, const void* a, cons
            (long long)B * H <= 65535 && (long long)B * H * N * N < (1ll << 32);
 }
 
-#define DH16_DISPATCH(kernel, nt, grid, s, p)                              \
+#define DH16_DISPATCH_T(kernel, T, nt, grid, s, p)                          \
     do {                                                                   \
-        if (nt <= 2) kernel<2><<<grid, 256, 0, s>>>(p);                     \
-        else if (nt <= 4) kernel<4><<<grid, 256, 0, s>>>(p);                \
-        else if (nt <= 7) kernel<7><<<grid, 256, 0, s>>>(p);                \
-        else if (nt <= 10) kernel<10><<<grid, 256, 0, s>>>(p);              \
-        else kernel<17><<<grid, 256, 0, s>>>(p);                            \
+        if (nt <= 2) kernel<2, T><<<grid, 256, 0, s>>>(p);                  \
+        else if (nt <= 4) kernel<4, T><<<grid, 256, 0, s>>>(p);             \
+        else if (nt <= 7) kernel<7, T><<<grid, 256, 0, s>>>(p);             \
+        else if (nt <= 10) kernel<10, T><<<grid, 256, 0, s>>>(p);           \
+        else kernel<17, T><<<grid, 256, 0, s>>>(p);                         \
+    } while (0)
+#define DH16_DISPATCH(kernel, io16, nt, grid, s, p)                        \
+    do {                                                                   \
+        if (io16) DH16_DISPATCH_T(kernel, bf16_t, nt, grid, s, p);         \
+        else DH16_DISPATCH_T(kernel, float, nt, grid, s, p);               \
     } while (0)
 
 }  // namespace
 
+extern "C" int medp_attn_dh16_train_supported(int B, int N, int H, int dh, int ld, int ldo) {
+    return B > 0 && N > 0 && H > 0 && dh > 0 && ld >= 3 * H * dh && ldo >= H * dh && supported(B, N, H, dh, ld, ldo, nullptr, nullptr) ? 1 : 0;
+}
+
 // returns -2 (nothing launched) for shapes these kernels are not built for: the caller then uses medp_attn_small_fwd / _bwd
-extern "C" int medp_attn_dh16_train_fwd(const float* qkv, int ld, float* o, int ldo, float* lse, int B, int N, int H, int dh, float scale,
-                                        float dropout_p, unsigned seed, unsigned stream_id, void* stream) {
+extern "C" int medp_attn_dh16_train_fwd(const void* qkv, int ld, void* o, int ldo, float* lse, int io_bf16, int B, int N, int H, int dh,
+                                        float scale, float dropout_p, unsigned seed, unsigned stream_id, void* stream) {
     MEDP_CHECK_ARG(qkv && o && lse && B > 0 && N > 0 && H > 0 && dh > 0, "attn_dh16_train_fwd: bad argument");
     MEDP_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f && scale > 0.f, "attn_dh16_train_fwd: dropout p / scale out of range");
     if (!supported(B, N, H, dh, ld, ldo, qkv, o)) return -2;
@@ -239,14 +266,14 @@ extern "C" int medp_attn_dh16_train_fwd(const float* qkv, int ld, float* o, int 
     const int nt = (N + 15) / 16;
     const dim3 grid((nt + 3) / 4, B * H);
     hipStream_t s = (hipStream_t)stream;
-    DH16_DISPATCH(dh16_train_fwd_kernel, nt, grid, s, p);
+    DH16_DISPATCH(dh16_train_fwd_kernel, io_bf16, nt, grid, s, p);
     MEDP_LAUNCH_CHECK("medp_attn_dh16_train_fwd");
     return 0;
 }
 
 // dqkv [B*N][lddqkv] receives dQ | dK | dV in the column blocks of qkv; delta_ws: B*H*N floats of scratch
-extern "C" int medp_attn_dh16_train_bwd(const float* dout, int lddo, const float* qkv, int ld, const float* lse, float* delta_ws, float* dqkv,
-                                        int lddqkv, int B, int N, int H, int dh, float scale, float dropout_p, unsigned seed,
+extern "C" int medp_attn_dh16_train_bwd(const void* dout, int lddo, const void* qkv, int ld, const float* lse, float* delta_ws, void* dqkv,
+                                        int lddqkv, int io_bf16, int B, int N, int H, int dh, float scale, float dropout_p, unsigned seed,
                                         unsigned stream_id, void* stream) {
     MEDP_CHECK_ARG(dout && qkv && lse && delta_ws && dqkv && B > 0 && N > 0 && H > 0 && dh > 0, "attn_dh16_train_bwd: bad argument");
     MEDP_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f && scale > 0.f, "attn_dh16_train_bwd: dropout p / scale out of range");
@@ -257,9 +284,9 @@ extern "C" int medp_attn_dh16_train_bwd(const float* dout, int lddo, const float
     const int nt = (N + 15) / 16;
     const dim3 grid((nt + 3) / 4, B * H);
     hipStream_t s = (hipStream_t)stream;
-    DH16_DISPATCH(dh16_train_bwd_dq_kernel, nt, grid, s, p);
+    DH16_DISPATCH(dh16_train_bwd_dq_kernel, io_bf16, nt, grid, s, p);
     MEDP_LAUNCH_CHECK("medp_attn_dh16_train_bwd(dq)");
-    DH16_DISPATCH(dh16_train_bwd_dkv_kernel, nt, grid, s, p);
+    DH16_DISPATCH(dh16_train_bwd_dkv_kernel, io_bf16, nt, grid, s, p);
     MEDP_LAUNCH_CHECK("medp_attn_dh16_train_bwd(dk, dv)");
     return 0;
 }

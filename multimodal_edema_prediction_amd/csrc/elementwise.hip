@@ -41,6 +41,38 @@ __global__ __launch_bounds__(256) void transpose_to_bf16_kernel(const TIN* __res
     }
 }
 
+// Every trainable weight's GEMM operands in ONE launch (graph_step's operand pool): block b converts the 64x64 tile blk_tile[b] of job
+// blk_job[b]: plain bf16 copy (forward operand, [rows, ld_plain]) and / or transposed bf16 copy (dX operand, [cols, ld_t]) of one fp32
+// matrix.  Same rounding as cast_f32_bf16_kernel / transpose_to_bf16_kernel (f2bf), so a pooled operand equals the one the
+// per-tensor kernels make, bit for bit.
+__global__ __launch_bounds__(256) void weight_operands_multi_kernel(const MedpOperandJob* __restrict__ jobs, const int* __restrict__ blk_job,
+                                                                    const int* __restrict__ blk_tile) {
+    __shared__ float tile[64][65];
+    const MedpOperandJob j = jobs[blk_job[blockIdx.x]];
+    const int tiles_c = (j.cols + 63) / 64;
+    const int t = blk_tile[blockIdx.x];
+    const int r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const float* x = (const float*)j.src;
+    bf16_t* yp = (bf16_t*)j.dst_plain;
+    bf16_t* yt = (bf16_t*)j.dst_t;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        float v = 0.f;
+        if (r < j.rows && c < j.cols) {
+            v = x[(size_t)r * j.ld_src + c];
+            if (yp) yp[(size_t)r * j.ld_plain + c] = f2bf(v);
+        }
+        tile[i][tx] = v;
+    }
+    if (!yt) return;
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < j.cols && r < j.rows) yt[(size_t)c * j.ld_t + r] = f2bf(tile[tx][i]);
+    }
+}
+
 // out = dy * gelu'(pre)     (pre-activation saved in fp32 or bf16)
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ dx,
                                                        size_t n) {
@@ -229,6 +261,14 @@ extern "C" int medp_transpose_to_bf16(const void* x, int x_is_bf16, int ldx, voi
     else
         transpose_to_bf16_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)x, ldx, (bf16_t*)y, ldy, rows, cols);
     MEDP_LAUNCH_CHECK("medp_transpose_to_bf16");
+    return 0;
+}
+
+extern "C" int medp_weight_operands_multi(const MedpOperandJob* dev_jobs, const int* dev_block_job, const int* dev_block_tile, int n_blocks,
+                                          void* stream) {
+    MEDP_CHECK_ARG(dev_jobs && dev_block_job && dev_block_tile && n_blocks > 0, "weight_operands_multi: bad argument");
+    weight_operands_multi_kernel<<<n_blocks, 256, 0, (hipStream_t)stream>>>(dev_jobs, dev_block_job, dev_block_tile);
+    MEDP_LAUNCH_CHECK("medp_weight_operands_multi");
     return 0;
 }
 

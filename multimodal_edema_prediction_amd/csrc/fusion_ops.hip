@@ -9,24 +9,28 @@ namespace {
 inline int grid_for(size_t work_items) { return (int)min((size_t)2048, max((size_t)1, (work_items + 255) / 256)); }
 
 // y = dropout(gelu(x))                        (nn.GELU -> nn.Dropout, model :755, :573)
-__global__ __launch_bounds__(256) void gelu_dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, float p,
+template <bool Y16>
+__global__ __launch_bounds__(256) void gelu_dropout_fwd_kernel(const float* __restrict__ x, void* __restrict__ y, size_t n, float p,
                                                                float inv_keep, uint32_t seed0, uint32_t sid, const uint32_t* __restrict__ epoch) {
     const uint32_t seed = medp_mix_epoch(seed0, epoch);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         float v = gelu_erf(x[i]);
         if (p > 0.f) v *= dropout_scale(seed, sid, (uint32_t)i, p, inv_keep);
-        y[i] = v;
+        if constexpr (Y16) ((bf16_t*)y)[i] = f2bf(v);          // the next Linear's operand directly (same rounding as the cast kernel)
+        else ((float*)y)[i] = v;
     }
 }
-// dx = dy * mask * gelu'(x)
+// dx = dy * mask * gelu'(x); DX16: also the bf16 copy the previous Linear's two gradient GEMMs take as their operand
+template <bool DX16>
 __global__ __launch_bounds__(256) void gelu_dropout_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                               float* __restrict__ dx, size_t n, float p, float inv_keep,
+                                                               float* __restrict__ dx, bf16_t* __restrict__ dx16, size_t n, float p, float inv_keep,
                                                                uint32_t seed0, uint32_t sid, const uint32_t* __restrict__ epoch) {
     const uint32_t seed = medp_mix_epoch(seed0, epoch);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         float g = dy[i] * gelu_erf_grad(x[i]);
         if (p > 0.f) g *= dropout_scale(seed, sid, (uint32_t)i, p, inv_keep);
         dx[i] = g;
+        if constexpr (DX16) dx16[i] = f2bf(g);
     }
 }
 // out = res + dropout(y)  (fwd, res may be null)   |   dy = dout * mask  (bwd: res == nullptr, y = dout)
@@ -327,15 +331,29 @@ __global__ __launch_bounds__(256) void masked_bce_kernel(const float* __restrict
 
 extern "C" int medp_gelu_dropout_fwd(const float* x, float* y, long long n, float p, unsigned seed, unsigned stream_id, void* stream) {
     MEDP_CHECK_ARG(x && y && n > 0 && p >= 0.f && p < 1.f, "gelu_dropout_fwd: bad argument");
-    gelu_dropout_fwd_kernel<<<grid_for((size_t)n), 256, 0, (hipStream_t)stream>>>(x, y, (size_t)n, p, 1.f / (1.f - p), seed, stream_id, medp_rng_epoch_ptr());
+    gelu_dropout_fwd_kernel<false><<<grid_for((size_t)n), 256, 0, (hipStream_t)stream>>>(x, y, (size_t)n, p, 1.f / (1.f - p), seed, stream_id, medp_rng_epoch_ptr());
     MEDP_LAUNCH_CHECK("medp_gelu_dropout_fwd");
+    return 0;
+}
+extern "C" int medp_gelu_dropout_fwd_bf16(const float* x, void* y_bf16, long long n, float p, unsigned seed, unsigned stream_id, void* stream) {
+    MEDP_CHECK_ARG(x && y_bf16 && n > 0 && p >= 0.f && p < 1.f, "gelu_dropout_fwd_bf16: bad argument");
+    gelu_dropout_fwd_kernel<true><<<grid_for((size_t)n), 256, 0, (hipStream_t)stream>>>(x, y_bf16, (size_t)n, p, 1.f / (1.f - p), seed, stream_id, medp_rng_epoch_ptr());
+    MEDP_LAUNCH_CHECK("medp_gelu_dropout_fwd_bf16");
     return 0;
 }
 extern "C" int medp_gelu_dropout_bwd(const float* dy, const float* x, float* dx, long long n, float p, unsigned seed,
                                      unsigned stream_id, void* stream) {
     MEDP_CHECK_ARG(dy && x && dx && n > 0 && p >= 0.f && p < 1.f, "gelu_dropout_bwd: bad argument");
-    gelu_dropout_bwd_kernel<<<grid_for((size_t)n), 256, 0, (hipStream_t)stream>>>(dy, x, dx, (size_t)n, p, 1.f / (1.f - p), seed, stream_id, medp_rng_epoch_ptr());
+    gelu_dropout_bwd_kernel<false><<<grid_for((size_t)n), 256, 0, (hipStream_t)stream>>>(dy, x, dx, nullptr, (size_t)n, p, 1.f / (1.f - p), seed, stream_id, medp_rng_epoch_ptr());
     MEDP_LAUNCH_CHECK("medp_gelu_dropout_bwd");
+    return 0;
+}
+extern "C" int medp_gelu_dropout_bwd_bf16(const float* dy, const float* x, float* dx, void* dx_bf16, long long n, float p, unsigned seed,
+                                          unsigned stream_id, void* stream) {
+    MEDP_CHECK_ARG(dy && x && dx && dx_bf16 && n > 0 && p >= 0.f && p < 1.f, "gelu_dropout_bwd_bf16: bad argument");
+    gelu_dropout_bwd_kernel<true><<<grid_for((size_t)n), 256, 0, (hipStream_t)stream>>>(dy, x, dx, (bf16_t*)dx_bf16, (size_t)n, p, 1.f / (1.f - p), seed, stream_id,
+                                                                                       medp_rng_epoch_ptr());
+    MEDP_LAUNCH_CHECK("medp_gelu_dropout_bwd_bf16");
     return 0;
 }
 extern "C" int medp_dropout_add(const float* y, const float* residual, float* out, long long n, float p, unsigned seed,

@@ -12,7 +12,7 @@ from . import autograd_ops as A
 from . import functional as Fn
 from .abi import check, lib, ptr, stream
 
-F32 = torch.float32
+F32, BF16 = torch.float32, torch.bfloat16
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 
 
@@ -253,7 +253,7 @@ class SelfAttnQKVFn(torch.autograd.Function):
         if _MFMA_ATTN and Fn.precision() != "fp32":
             o = torch.empty((B, N, D), dtype=torch.float32, device=qkv.device)
             lse = torch.empty((B * H * N,), dtype=torch.float32, device=qkv.device)
-            rc = lib().medp_attn_dh16_train_fwd(ptr(qkv), D3, ptr(o), D, ptr(lse), B, N, H, dh, dh ** -0.5, p, seed, sid, stream())
+            rc = lib().medp_attn_dh16_train_fwd(ptr(qkv), D3, ptr(o), D, ptr(lse), 0, B, N, H, dh, dh ** -0.5, p, seed, sid, stream())
             if rc != -2:
                 check(rc, "attn_dh16_train_fwd")
                 ctx.save_for_backward(qkv, lse)
@@ -275,7 +275,7 @@ class SelfAttnQKVFn(torch.autograd.Function):
         if len(ctx.saved_tensors) == 2:                       # the forward ran on the matrix cores: so does the backward
             lse = ctx.saved_tensors[1]
             delta = torch.empty_like(lse)
-            check(lib().medp_attn_dh16_train_bwd(ptr(do2), D, ptr(qkv), D3, ptr(lse), ptr(delta), ptr(dqkv), D3, B, N, H, dh, dh ** -0.5, p, seed,
+            check(lib().medp_attn_dh16_train_bwd(ptr(do2), D, ptr(qkv), D3, ptr(lse), ptr(delta), ptr(dqkv), D3, 0, B, N, H, dh, dh ** -0.5, p, seed,
                                                  sid, stream()), "attn_dh16_train_bwd")
             return dqkv, None, None, None, None
         base = dqkv.data_ptr()
@@ -283,6 +283,121 @@ class SelfAttnQKVFn(torch.autograd.Function):
                                         base + 4 * D, D3, base + 8 * D, 0, N * D3, B, N, N, H, dh, dh ** -0.5, p, seed, sid, stream()),
               "attn_small_bwd(qkv)")
         return dqkv, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ fused halves of an encoder block
+_FUSED_NODES = __import__("os").environ.get("MEDP_DUETT_FUSED_NODES", "1") == "1"
+
+
+def _scalenorm_bwd_into(dh, x, g, rn, d_pass):
+    """d_pass += d ScaleNorm(x) / dx applied to dh (in place: `d_pass` is the gradient of the half's output, which the residual hands
+    straight through); returns dg [1]."""
+    x2 = x.view(-1, x.shape[-1])
+    rows, D = x2.shape
+    dg = torch.empty(1, dtype=F32, device=x.device)
+    ws = torch.empty(rows, dtype=F32, device=x.device)
+    check(lib().medp_scalenorm_bwd(ptr(dh), D, ptr(x2), D, ptr(g), ptr(rn), ptr(d_pass), D, 1, ptr(dg), ptr(ws), rows, D, stream()),
+          "scalenorm_bwd(accumulate)")
+    return dg
+
+
+class AttnHalfFn(torch.autograd.Function):
+    """x + to_out(Attention(ScaleNorm(x)))  — the attention half of an x_transformers pre-norm block (duett/duett.py:95-105) as ONE autograd
+    node with 16-bit hand-overs inside: ScaleNorm writes the qkv GEMM's bf16 operand, that GEMM writes bf16 q | k | v, the MFMA attention
+    (csrc/attention_dh16_train.hip, io_bf16 = 1) reads them and writes bf16 o, the out-projection adds the residual in its epilogue.
+    Backward: one cast of dY, then dO, dQ | dK | dV in bf16 between the kernels, and the ScaleNorm backward accumulated into dY.
+    Every value is rounded to bf16 exactly where the separate nodes (ScaleNormFn -> LinearFn -> SelfAttnQKVFn -> LinearFn) round it, so
+    the results are bit-identical; 13 cast / transpose / concatenation launches per block and step fewer."""
+
+    @staticmethod
+    def forward(ctx, x, g, eps, wq, wk, wv, wo, H, p, seed, sid):
+        xc = x.contiguous()
+        B, N, D = xc.shape
+        ws = (wq, wk, wv)
+        Dv = wq.shape[0]
+        dh = Dv // H
+        h16, rn = Fn.scalenorm(xc, g, eps, out_dtype=BF16, save_rnorm=True)
+        qkv16 = Fn.gemm(h16.view(B * N, D), A.weights_cat_bf16(ws), out_dtype=BF16, k=D)             # [B*N, 3 Dv]
+        o16 = torch.empty((B * N, Dv), dtype=BF16, device=x.device)
+        lse = torch.empty((B * H * N,), dtype=F32, device=x.device)
+        check(lib().medp_attn_dh16_train_fwd(ptr(qkv16), 3 * Dv, ptr(o16), Dv, ptr(lse), 1, B, N, H, dh, dh ** -0.5, p, seed, sid, stream()),
+              "attn_dh16_train_fwd(bf16)")
+        y = Fn.gemm(o16, A.weight_bf16(wo), residual=xc.view(B * N, D), out_dtype=F32, k=Dv)
+        ctx.save_for_backward(xc, g, rn, h16, qkv16, lse, o16, wq, wk, wv, wo)
+        ctx.cfg = (H, p, seed, sid)
+        return y.view(B, N, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, g, rn, h16, qkv16, lse, o16, wq, wk, wv, wo = ctx.saved_tensors
+        H, p, seed, sid = ctx.cfg
+        B, N, D = xc.shape
+        ws = (wq, wk, wv)
+        Dv = wq.shape[0]
+        dh = Dv // H
+        dy2 = dy.contiguous().view(B * N, D)
+        dy16 = Fn.operand(dy2)
+        do16 = Fn.gemm(dy16, A.weight_t_bf16(wo), out_dtype=BF16, k=D)                                # [B*N, Dv]
+        dwo = Fn.gemm_tn(dy16, o16)
+        dqkv16 = torch.empty_like(qkv16)
+        delta = torch.empty_like(lse)
+        check(lib().medp_attn_dh16_train_bwd(ptr(do16), do16.stride(0), ptr(qkv16), 3 * Dv, ptr(lse), ptr(delta), ptr(dqkv16), 3 * Dv, 1, B, N, H,
+                                             dh, dh ** -0.5, p, seed, sid, stream()), "attn_dh16_train_bwd(bf16)")
+        dhid = Fn.gemm(dqkv16, A.weights_cat_t_bf16(ws), out_dtype=F32, k=3 * Dv)                     # [B*N, D]
+        dwq, dwk, dwv = Fn.gemm_tn(dqkv16, h16.view(B * N, D)).split([w.shape[0] for w in ws], 0)
+        dg = _scalenorm_bwd_into(dhid, xc, g, rn, dy2)
+        return dy2.view(B, N, D), dg, None, dwq, dwk, dwv, dwo, None, None, None, None
+
+
+class FeedForwardHalfFn(torch.autograd.Function):
+    """x + W2 dropout(gelu(W1 ScaleNorm(x) + b1)) + b2  — the feed-forward half as ONE node: ScaleNorm writes W1's bf16 operand, GELU + dropout
+    write W2's, the residual rides in W2's epilogue; the backward casts dY once and `medp_gelu_dropout_bwd_bf16` writes d(pre-activation) in
+    fp32 (bias gradient) and bf16 (operand of both W1 gradient GEMMs).  Bit-identical to the separate nodes."""
+
+    @staticmethod
+    def forward(ctx, x, g, eps, w1, b1, w2, b2, p, seed, sid):
+        xc = x.contiguous()
+        B, N, D = xc.shape
+        h16, rn = Fn.scalenorm(xc, g, eps, out_dtype=BF16, save_rnorm=True)
+        f = Fn.gemm(h16.view(B * N, D), A.weight_bf16(w1), bias=b1, out_dtype=F32, k=D)               # pre-activation, kept for the backward
+        a16 = torch.empty(f.shape, dtype=BF16, device=x.device)
+        check(lib().medp_gelu_dropout_fwd_bf16(ptr(f), ptr(a16), f.numel(), p, seed, sid, stream()), "gelu_dropout_fwd_bf16")
+        y = Fn.gemm(a16, A.weight_bf16(w2), bias=b2, residual=xc.view(B * N, D), out_dtype=F32, k=w2.shape[1])
+        ctx.save_for_backward(xc, g, rn, h16, f, a16, w1, w2)
+        ctx.cfg = (p, seed, sid)
+        return y.view(B, N, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, g, rn, h16, f, a16, w1, w2 = ctx.saved_tensors
+        p, seed, sid = ctx.cfg
+        B, N, D = xc.shape
+        dy2 = dy.contiguous().view(B * N, D)
+        dy16 = Fn.operand(dy2)
+        da = Fn.gemm(dy16, A.weight_t_bf16(w2), out_dtype=F32, k=D)                                   # [B*N, hidden]
+        dw2 = Fn.gemm_tn(dy16, a16)
+        db2 = Fn.colsum(dy2)
+        df = torch.empty_like(f)
+        df16 = torch.empty(f.shape, dtype=BF16, device=f.device)
+        check(lib().medp_gelu_dropout_bwd_bf16(ptr(da), ptr(f), ptr(df), ptr(df16), f.numel(), p, seed, sid, stream()), "gelu_dropout_bwd_bf16")
+        dhid = Fn.gemm(df16, A.weight_t_bf16(w1), out_dtype=F32, k=w1.shape[0])                       # [B*N, D]
+        dw1 = Fn.gemm_tn(df16, h16.view(B * N, D))
+        db1 = Fn.colsum(df)
+        dg = _scalenorm_bwd_into(dhid, xc, g, rn, dy2)
+        return dy2.view(B, N, D), dg, None, dw1, db1, dw2, db2, None, None, None
+
+
+def _fused_nodes_ok(m, x):
+    """The fused halves take the shapes the MFMA attention and the transposing weight-gradient GEMM take, in bf16 kernel mode."""
+    if not (_FUSED_NODES and _MFMA_ATTN and _FOLD_RESIDUAL_ADD) or Fn.precision() == "fp32" or not x.requires_grad:
+        return False
+    a, ff = m.layers[0][1], m.layers[1][1].ff
+    B, N, D = x.shape
+    Dv = a.to_q.weight.shape[0]
+    dh = Dv // m.heads
+    hid = ff[0][0].weight.shape[0]
+    return (D % 8 == 0 and Dv % 8 == 0 and hid % 8 == 0 and a.to_out.bias is None and ff[0][0].bias is not None and ff[2].bias is not None
+            and lib().medp_attn_dh16_train_supported(B, N, m.heads, dh, 3 * Dv, Dv) == 1)
 
 
 # ------------------------------------------------------------------------------------------------ the composition
@@ -317,10 +432,14 @@ def encoder_training(m, x, eps, final_norm, training, seed, sid):
     """One x_transformers-style encoder block (see oracle/xt_encoder.py) on x [B, N, D]."""
     a, ff = m.layers[0][1], m.layers[1][1].ff
     p = float(m.dropout) if training else 0.0
+    if _fused_nodes_ok(m, x):
+        x = AttnHalfFn.apply(x, m.layers[0][0][0].g, eps, a.to_q.weight, a.to_k.weight, a.to_v.weight, a.to_out.weight, m.heads, p, seed, sid)
+        x = FeedForwardHalfFn.apply(x, m.layers[1][0][0].g, eps, ff[0][0].weight, ff[0][0].bias, ff[2].weight, ff[2].bias, p, seed, sid + 1)
+        return ScaleNormFn.apply(x, m.final_norm.g, eps) if final_norm else x
     norm = (lambda t, g: ResidualScaleNormFn.apply(t, g, eps)) if (_FOLD_RESIDUAL_ADD and x.requires_grad) else \
         (lambda t, g: (t, ScaleNormFn.apply(t, g, eps)))
     x, h = norm(x, m.layers[0][0][0].g)
-    qkv = A.linear(h, torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight], 0))
+    qkv = A.linear_cat(h, (a.to_q.weight, a.to_k.weight, a.to_v.weight))
     o = SelfAttnQKVFn.apply(qkv, m.heads, p, seed, sid)
     x = A.linear(o, a.to_out.weight, None, residual=x)
     x, h = norm(x, m.layers[1][0][0].g)

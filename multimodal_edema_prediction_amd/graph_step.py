@@ -33,7 +33,7 @@ import os
 
 import torch
 
-from . import dp, engine
+from . import autograd_ops as _A, dp, engine
 from .streams import new_stream, note_capture_origin
 from .abi import check, lib, ptr, stream
 
@@ -94,6 +94,7 @@ class _GraphedStep:
         self.arena = None
         self.force_collective = False      # bench.py MEDP_FORCE_PG=1: really call RCCL on a size-1 group (one-GPU rehearsal of N > 1)
         self._captured = False
+        self._pool = None                  # autograd_ops.WeightOperandPool, built from the last warm-up step
         # the frozen forward may itself be cut into sub-batches on sibling streams (`_n_frozen_parts`): every one is forked from
         # the step's own stream — a fork nested inside a forked branch crashes hipStreamEndCapture on this runtime
         self.frozen_streams = [new_stream(device) for _ in range(self._n_frozen_parts())] if self.pipeline else []
@@ -116,7 +117,13 @@ class _GraphedStep:
                         m.get_buffer(n).copy_(saved)
                 self._zero_grads()
                 self._advance()
-                self._whole_fwd_bwd()
+                if it == max(int(warmup), 1) - 1 and os.environ.get("MEDP_OPERAND_POOL", "1") == "1":
+                    # which trainable weights the step asks GEMM operands of: from the capture on ONE launch makes them all
+                    with _A.record_operands() as log:
+                        self._whole_fwd_bwd()
+                    self._pool = _A.WeightOperandPool(log, device)
+                else:
+                    self._whole_fwd_bwd()
                 self._allreduce()
                 self.opt.step()
         torch.cuda.current_stream(device).wait_stream(s)
@@ -152,7 +159,6 @@ class _GraphedStep:
         # and into the cached bf16 copies of frozen Linear weights.  Those are rebuilt — and the old tensors freed — when somebody
         # writes a frozen parameter or buffer and then calls the module eagerly: keep what the capture saw alive, and refuse to
         # replay over changed weights (`_replay`) instead of training on stale ones.
-        from . import autograd_ops as _A
         self._prep_refs = [(m, m._prep) for root in self._stateful_modules() for m in root.modules() if getattr(m, "_prep", None) is not None]
         self._cache_refs = [v for slot in _A._W_CACHE.values() for v in slot.values()]
         # ... and into the modules' workspaces and pointer / length tables: an eager call with a larger batch or image
@@ -263,6 +269,8 @@ class _GraphedStep:
 
     def _advance(self):
         check(lib().medp_counter_advance(ptr(self.epoch), stream()), "counter_advance")
+        if self._pool is not None:
+            self._pool.refresh()           # bf16 operands of every trainable weight for this step: one launch
 
     def _allreduce(self):
         if self.arena is not None and (self.world > 1 or self.force_collective):

@@ -30,7 +30,11 @@ __all__ = ["DuettFeatureExtractor", "load_duett_backbone", "CXREncoder", "PatchD
 # dropout stream ids (one per dropout site; combined with a per-forward seed)
 import os as _os
 
-_OVERLAP_MODE = int(_os.environ.get("MEDP_OVERLAP", "1"))   # 0 = one stream, 1 = whole TS half beside the CXR encoder, 2 = DuETT encoder only
+# 0 = one stream, 1 = whole TS half beside the CXR encoder, 2 = DuETT encoder only.  Unset: 1 when this forward runs the CXR encoder itself,
+# 0 when the encoder's tokens are handed in (graph_step's pipelined step: the encoder is not in this forward, and a third branch beside the
+# NEXT batch's encoder measured 2 % slower than none, profiles/r03_ab_experiments.txt)
+_OVERLAP_ENV = _os.environ.get("MEDP_OVERLAP")
+_OVERLAP_MODE = int(_OVERLAP_ENV) if _OVERLAP_ENV is not None else 1
 _OVERLAP = _OVERLAP_MODE != 0
 _SIDE_STREAMS: dict = {}
 if _OVERLAP and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
@@ -359,7 +363,8 @@ class TeacherModel(nn.Module):
         # GEMMs they fill otherwise idle issue slots.  autograd replays each node's backward on its forward stream, so the
         # two halves of the backward overlap the same way.  MEDP_OVERLAP=0 runs everything on one stream.
         cur = torch.cuda.current_stream()
-        side = _side_stream(pixel_values.device) if (_OVERLAP and _overlap is not False) else None
+        mode = _OVERLAP_MODE if (_OVERLAP_ENV is not None or _cxr_tokens16 is None) else 0
+        side = _side_stream(pixel_values.device) if (mode != 0 and _overlap is not False) else None
         if side is not None:
             from .streams import fork_guard
             fork_guard("TeacherModel.forward", pixel_values.device)         # raises instead of a crash in capture_end (nested fork)
@@ -369,9 +374,9 @@ class TeacherModel(nn.Module):
                     t.record_stream(side)
             with torch.cuda.stream(side):
                 ts_tokens = self.duett.encode(duett_in)                     # [B, T+1, D]
-                if _OVERLAP_MODE == 1:
+                if mode == 1:
                     ts = pc._ts_branch(pc._select_ts(ts_tokens, "hourly_only"), q0, seed, return_attn)
-            if _OVERLAP_MODE != 1:                                          # encoder only on the side stream
+            if mode != 1:                                                   # encoder only on the side stream
                 cur.wait_stream(side)
                 ts_tokens.record_stream(cur)
                 ts = pc._ts_branch(pc._select_ts(ts_tokens, "hourly_only"), q0, seed, return_attn)

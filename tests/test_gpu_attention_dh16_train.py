@@ -24,18 +24,33 @@ def _ref(qkv, do, H):
     return o.detach(), x.grad
 
 
-def _call(qkv, do, H, p=0.0, seed=0, sid=0):
+def _call(qkv, do, H, p=0.0, seed=0, sid=0, io16=False):
     from multimodal_edema_prediction_amd.abi import check, lib, ptr, stream
     B, N, D3 = qkv.shape
     D = D3 // 3
     dh = D // H
-    o = torch.empty(B, N, D, device=DEV)
+    if io16:
+        qkv, do = qkv.to(torch.bfloat16), do.to(torch.bfloat16)
+    o = torch.empty(B, N, D, device=DEV, dtype=qkv.dtype)
     lse, delta = torch.empty(B * H * N, device=DEV), torch.empty(B * H * N, device=DEV)
     dqkv = torch.full_like(qkv, float("nan"))
-    check(lib().medp_attn_dh16_train_fwd(ptr(qkv), D3, ptr(o), D, ptr(lse), B, N, H, dh, dh ** -0.5, p, seed, sid, stream()), "fwd")
-    check(lib().medp_attn_dh16_train_bwd(ptr(do), D, ptr(qkv), D3, ptr(lse), ptr(delta), ptr(dqkv), D3, B, N, H, dh, dh ** -0.5, p, seed, sid,
-                                         stream()), "bwd")
+    check(lib().medp_attn_dh16_train_fwd(ptr(qkv), D3, ptr(o), D, ptr(lse), int(io16), B, N, H, dh, dh ** -0.5, p, seed, sid, stream()), "fwd")
+    check(lib().medp_attn_dh16_train_bwd(ptr(do), D, ptr(qkv), D3, ptr(lse), ptr(delta), ptr(dqkv), D3, int(io16), B, N, H, dh, dh ** -0.5, p,
+                                         seed, sid, stream()), "bwd")
     return o, dqkv
+
+
+@pytest.mark.parametrize("B,N,H,dh,p", [(5, 97, 2, 12, 0.0), (7, 49, 2, 12, 0.3), (2, 130, 1, 16, 0.1), (1, 5, 3, 4, 0.0)])
+def test_bf16_hand_over_form_has_the_bits_of_the_fp32_form(B, N, H, dh, p):
+    """io_bf16 = 1 reads bf16 q | k | v / dO and writes bf16 o / dQ | dK | dV: the fp32 form rounds the same fp32 values to the same MFMA
+    operands, so on inputs that are exactly representable in bf16 both compute the same numbers and differ only by the final rounding."""
+    torch.manual_seed(3)
+    qkv = (torch.randn(B, N, 3 * H * dh) * 0.8).to(DEV).to(torch.bfloat16).float()
+    do = torch.randn(B, N, H * dh).to(DEV).to(torch.bfloat16).float()
+    o32, g32 = _call(qkv, do, H, p, seed=5, sid=3)
+    o16, g16 = _call(qkv, do, H, p, seed=5, sid=3, io16=True)
+    assert o16.dtype == torch.bfloat16 and g16.dtype == torch.bfloat16 and not torch.isnan(g16.float()).any()
+    assert torch.equal(o16, o32.to(torch.bfloat16)) and torch.equal(g16, g32.to(torch.bfloat16))
 
 
 @pytest.mark.parametrize("B,N,H,dh", [(5, 97, 2, 12), (7, 49, 2, 12), (3, 17, 2, 12), (2, 130, 1, 16), (2, 257, 2, 8), (1, 5, 3, 4)])

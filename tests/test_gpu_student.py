@@ -126,3 +126,46 @@ def test_student_engine_step():
         np.testing.assert_allclose(float(p.detach().double().abs().sum()), gold["post:" + k][1], rtol=3e-4, atol=3e-3)
         n += 1
     assert n > 50
+
+
+def _student_grads(dropout, fused, pool):
+    """One forward / backward of the student at a fixed dropout seed; (logits, {name: grad})."""
+    from multimodal_edema_prediction_amd import autograd_ops as A, duett_train as DT
+    torch.manual_seed(11)
+    bb = DuettFeatureExtractor(d_static_num=DS, d_time_series_num=V, d_target=1, pretrain=False, masked_transform_timesteps=T, max_len=T,
+                               aug_noise=0.0, aug_mask=0.0, transformer_dropout=dropout)
+    s = StudentModel(bb, pool="mean", head_hidden=128, head_dropout=0.0)
+    s.load_state_dict(synth_state_dict(SHAPES["student"], seed=2), strict=True)
+    s = s.to(DEV).train()
+    b = engine._move_lists(make_batch(CCFG, META["teacher_batch_start"], B, mode="student"), DEV)
+    prev = DT._FUSED_NODES
+    DT._FUSED_NODES = fused
+    try:
+        if pool:
+            with A.record_operands() as log:                       # a first pass tells which operands the step asks for
+                s(b["x_ts"], b["x_static"], b["bin_ends"]).sum().backward()
+            s.zero_grad()
+            wp = A.WeightOperandPool(log, torch.device(DEV))
+            assert wp.n_jobs >= 16
+            for prm in s.parameters():                             # as after an optimiser update: every cached operand is stale
+                torch.autograd.graph.increment_version(prm)
+            wp.refresh()
+        torch.manual_seed(5)                                       # A.next_seed() draws the dropout seed from the CPU generator
+        z = s(b["x_ts"], b["x_static"], b["bin_ends"])
+        (z * torch.linspace(-1, 1, z.numel(), device=DEV).view_as(z)).sum().backward()
+    finally:
+        DT._FUSED_NODES = prev
+    return z.detach().clone(), {k: p.grad.detach().clone() for k, p in s.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.2])
+def test_fused_encoder_halves_and_operand_pool_are_bit_identical_to_the_separate_nodes(dropout):
+    """AttnHalfFn / FeedForwardHalfFn (16-bit hand-overs inside one autograd node) and WeightOperandPool (all weight operands from one
+    launch) round every value where the separate nodes round it: logits and every gradient are the same bits."""
+    z0, g0 = _student_grads(dropout, fused=False, pool=False)
+    for fused, pool in ((True, False), (False, True), (True, True)):
+        z1, g1 = _student_grads(dropout, fused=fused, pool=pool)
+        assert torch.equal(z0, z1), (fused, pool, float((z0 - z1).abs().max()))
+        assert g0.keys() == g1.keys()
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]), (fused, pool, k, float((g0[k] - g1[k]).abs().max()))

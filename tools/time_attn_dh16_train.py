@@ -14,8 +14,8 @@ for P in (0.0, 0.1):
       qkv = torch.randn(B, N, 3 * D, device="cuda")
       do = torch.randn(B, N, D, device="cuda")
       o = torch.empty(B, N, D, device="cuda"); lse = torch.empty(B * H * N, device="cuda"); delta = torch.empty_like(lse); dqkv = torch.empty_like(qkv)
-      f = lambda: check(lib().medp_attn_dh16_train_fwd(ptr(qkv), 3 * D, ptr(o), D, ptr(lse), B, N, H, dh, dh ** -0.5, P, 1, 2, stream()), "f")
-      b = lambda: check(lib().medp_attn_dh16_train_bwd(ptr(do), D, ptr(qkv), 3 * D, ptr(lse), ptr(delta), ptr(dqkv), 3 * D, B, N, H, dh, dh ** -0.5, P, 1, 2, stream()), "b")
+      f = lambda: check(lib().medp_attn_dh16_train_fwd(ptr(qkv), 3 * D, ptr(o), D, ptr(lse), 0, B, N, H, dh, dh ** -0.5, P, 1, 2, stream()), "f")
+      b = lambda: check(lib().medp_attn_dh16_train_bwd(ptr(do), D, ptr(qkv), 3 * D, ptr(lse), ptr(delta), ptr(dqkv), 3 * D, 0, B, N, H, dh, dh ** -0.5, P, 1, 2, stream()), "b")
       fv = lambda: Fn.attn_small_fwd(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], B, N, N, H, dh, dh ** -0.5, q_batch_stride=N * 3 * D, kv_batch_stride=N * 3 * D, dropout_p=P, seed=1, stream_id=2)
       base = dqkv.data_ptr()
       bv = lambda: check(lib().medp_attn_small_bwd(ptr(do), D, ptr(qkv), 3 * D, N * 3 * D, qkv.data_ptr() + 4 * D, qkv.data_ptr() + 8 * D, 3 * D, N * 3 * D, base, 3 * D,
