@@ -360,6 +360,21 @@ int medp_glinear_fwd(const float* x, const float* W, const float* b, float* y, i
 size_t medp_glinear_bwd_workspace_bytes(int G, int R, int K, int N);
 int medp_glinear_bwd(const float* dy, const float* x, const float* W, float* dx, float* dW, float* db, float* workspace, int G, int R,
                      int K, int N, void* stream);
+/* The per-variable embedding MLP Linear(KIN, C) -> ReLU -> BatchNormLastDim(C) -> Linear(C, E) (duett/duett.py:24-39 `simple_mlp` with
+ * hidden_batch_norm, model file :45-55) of ALL variables as fused kernels that never store the hidden activations (csrc/duett_embed_train.hip):
+ * x [G][R][KIN], W0 [G][C][KIN], b0 / bn_w / bn_b / running_* / save_* [G][C], W1 [G][E][C], b1 [G][E], out [G][R][E].  batch_stats = 1:
+ * train() (batch statistics normalise, running statistics updated in place), 0: eval().  Built for (KIN, C, E) = (2, 64, 24) — the
+ * reference's defaults; medp_gmlp_supported says so, the entry points return -2 otherwise (use medp_glinear_* / medp_gbn_* / medp_act_*).
+ * bwd: dx may be NULL; every other gradient is written (dbn_w / dbn_b: BatchNorm weight / bias).  Bitwise reproducible. */
+int medp_gmlp_supported(int KIN, int C, int E);
+size_t medp_gmlp_workspace_bytes(int G, int R, int KIN, int C, int E);
+int medp_gmlp_fwd(const float* x, const float* W0, const float* b0, const float* bn_w, const float* bn_b, float* running_mean,
+                  float* running_var, const float* W1, const float* b1, float* out, float* save_mean, float* save_var, int G, int R,
+                  int KIN, int C, int E, float eps, float momentum, int batch_stats, float* workspace, void* stream);
+int medp_gmlp_bwd(const float* dout, const float* x, const float* W0, const float* b0, const float* bn_w, const float* bn_b,
+                  const float* save_mean, const float* save_var, const float* W1, float* dx, float* dW0, float* db0, float* dbn_w,
+                  float* dbn_b, float* dW1, float* db1, int G, int R, int KIN, int C, int E, float eps, int batch_stats,
+                  float* workspace, void* stream);
 /* BatchNormLastDim over the R rows of every group (duett/duett.py:11-22): batch_stats=1 train (biased var normalises,
  * unbiased updates running), 0 eval.  save_mean/save_var [G,C] feed the backward. */
 size_t medp_gbn_workspace_bytes(int G, int R, int C);   /* per-chunk partial sums of the two-stage (deterministic) row reductions */

@@ -124,6 +124,10 @@ SIGNATURES = {
     "medp_glinear_fwd": (I, [P, P, P, P, I, I, I, I, P]),
     "medp_glinear_bwd_workspace_bytes": (SZ, [I, I, I, I]),
     "medp_glinear_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, P]),
+    "medp_gmlp_supported": (I, [I, I, I]),
+    "medp_gmlp_workspace_bytes": (SZ, [I, I, I, I, I]),
+    "medp_gmlp_fwd": (I, [P] * 12 + [I, I, I, I, I, F, F, I, P, P]),
+    "medp_gmlp_bwd": (I, [P] * 16 + [I, I, I, I, I, F, I, P, P]),
     "medp_gbn_workspace_bytes": (SZ, [I, I, I]),
     "medp_gbn_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, F, F, I, P, P]),
     "medp_gbn_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, F, I, P, P]),

@@ -1,0 +1,377 @@
+// The per-variable embedding MLP of DuETT in TRAINING form as fused kernels (student KD path; reference duett/duett.py:11-39 `simple_mlp`
+// = Linear(2, C) -> ReLU -> BatchNormLastDim(C) -> Linear(C, E), one per variable, model file :45-55), group = variable:
+//     x [G][R][KIN]  ->  a = relu(W0 x + b0)  ->  hb = BN_train(a)  ->  out = W1 hb + b1   [G][R][E]
+// The grouped-layer kernels of duett_train.hip materialise a and hb ([48][6144][64] fp32 = 75 MB each at cfg3) and walk them with seven
+// forward and ~twenty backward launches (0.24 + 0.43 ms per student step, profiles/r03_kerneltrace_bench_student.txt).  With KIN = 2 the
+// hidden row costs two FMAs per channel to recompute, so here NOTHING of size C is ever stored: the forward is a statistics pass and an
+// output pass over x (2.4 MB), the backward two passes over (x, dout) that recompute a / xhat / dhb in registers.
+//   lane = hidden channel c (C = 64 = one wave), a wave walks rows; row-uniform values (x[r][:], dout[r][:]) come from one coalesced
+//   load + v_readlane, so the FMAs take them as scalar operands.  Sums over rows are per-lane accumulators, combined across waves and
+//   row chunks in a fixed order: bitwise reproducible, no atomics.
+#include "common.h"
+#include "medp_hip.h"
+
+namespace {
+
+constexpr int C = 64;          // hidden width = lanes of a wave
+constexpr int ST_RPC = 128;    // rows per workgroup of the statistics pass (same chunking as gbn_stats_partial_kernel)
+constexpr int BW_RPC = 512;    // rows per workgroup of the two backward passes (4 waves x 128 rows)
+inline int st_chunks(int R) { return (R + ST_RPC - 1) / ST_RPC; }
+inline int bw_chunks(int R) { return (R + BW_RPC - 1) / BW_RPC; }
+
+template <int KIN>
+struct HiddenPar {             // what a lane (= channel c of group g) needs to rebuild its hidden value
+    float w0[KIN], b0, mu, rs, bw, bb;
+};
+template <int KIN>
+__device__ __forceinline__ float pre_act(const HiddenPar<KIN>& p, const float* xr) {
+    float a = p.b0;
+#pragma unroll
+    for (int k = 0; k < KIN; ++k) a += p.w0[k] * xr[k];       // bias first, ascending k: the order of glinear_fwd_kernel
+    return a;
+}
+
+// ---- forward, pass 1: shifted sums of a = relu(W0 x + b0) per (g, c) and row chunk (pivot = the group's first row) --------------
+template <int KIN>
+__global__ __launch_bounds__(256) void gmlp_stats_partial_kernel(const float* __restrict__ x, const float* __restrict__ W0,
+                                                                 const float* __restrict__ b0, float* __restrict__ part, int R) {
+    __shared__ float red[2][4][C];
+    const int g = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    HiddenPar<KIN> p;
+#pragma unroll
+    for (int k = 0; k < KIN; ++k) p.w0[k] = W0[((size_t)g * C + c) * KIN + k];
+    p.b0 = b0[(size_t)g * C + c];
+    const float* xg = x + (size_t)g * R * KIN;
+    const float pivot = fmaxf(pre_act<KIN>(p, xg), 0.f);
+    const int r0 = chunk * ST_RPC, r1 = min(R, r0 + ST_RPC);
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = r0 + rl; r < r1; r += 4) {
+        const float d = fmaxf(pre_act<KIN>(p, xg + (size_t)r * KIN), 0.f) - pivot;
+        s1 += d;
+        s2 += d * d;
+    }
+    red[0][rl][c] = s1;
+    red[1][rl][c] = s2;
+    __syncthreads();
+    if (rl == 0) {
+        float* o = part + (((size_t)g * nchunk + chunk) * 2) * C;
+        o[c] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+        o[C + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    }
+}
+// chunks added in order; mean / biased variance saved for the backward; running statistics updated as gbn_running_kernel does
+template <int KIN>
+__global__ __launch_bounds__(256) void gmlp_stats_final_kernel(const float* __restrict__ x, const float* __restrict__ W0, const float* __restrict__ b0,
+                                                               const float* __restrict__ part, float* __restrict__ mean, float* __restrict__ var,
+                                                               float* __restrict__ rmean, float* __restrict__ rvar, int G, int R, int nchunk,
+                                                               float momentum) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= G * C) return;
+    const int g = i / C, c = i - g * C;
+    HiddenPar<KIN> p;
+#pragma unroll
+    for (int k = 0; k < KIN; ++k) p.w0[k] = W0[(size_t)i * KIN + k];
+    p.b0 = b0[i];
+    const float pivot = fmaxf(pre_act<KIN>(p, x + (size_t)g * R * KIN), 0.f);
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < nchunk; ++k) {
+        const float* o = part + (((size_t)g * nchunk + k) * 2) * C;
+        s1 += o[c];
+        s2 += o[C + c];
+    }
+    const float m1 = s1 / (float)R;
+    const float mu = pivot + m1, v = fmaxf(s2 / (float)R - m1 * m1, 0.f);
+    mean[i] = mu;
+    var[i] = v;
+    if (rmean && rvar) {
+        rmean[i] = (1.f - momentum) * rmean[i] + momentum * mu;
+        rvar[i] = (1.f - momentum) * rvar[i] + momentum * v * ((float)R / (float)max(R - 1, 1));
+    }
+}
+
+// ---- forward, pass 2: out[r][:] = b1 + W1 BN(relu(W0 x[r] + b0)); a thread owns a row and its E accumulators, the group's parameters
+// are broadcast out of LDS (one 16-byte read serves the wave) ------------------------------------------------------------------------
+template <int KIN, int E>
+__global__ __launch_bounds__(256) void gmlp_out_kernel(const float* __restrict__ x, const float* __restrict__ W0, const float* __restrict__ b0,
+                                                       const float* __restrict__ bn_w, const float* __restrict__ bn_b, const float* __restrict__ mean,
+                                                       const float* __restrict__ var, const float* __restrict__ W1, const float* __restrict__ b1,
+                                                       float* __restrict__ out, int R, float eps) {
+    static_assert(E % 4 == 0 && KIN <= 3, "layout");
+    __shared__ __attribute__((aligned(16))) float s_par[C][8];      // w0[KIN] | b0 | mu | rs | w | b  (KIN + 5 <= 8)
+    __shared__ __attribute__((aligned(16))) float s_w1[C][E];       // W1 transposed: [c][n]
+    const int g = blockIdx.y;
+    for (int i = threadIdx.x; i < C; i += 256) {
+        const size_t gc = (size_t)g * C + i;
+#pragma unroll
+        for (int k = 0; k < KIN; ++k) s_par[i][k] = W0[gc * KIN + k];
+        s_par[i][KIN] = b0[gc];
+        s_par[i][KIN + 1] = mean[gc];
+        s_par[i][KIN + 2] = rsqrtf(var[gc] + eps);
+        s_par[i][KIN + 3] = bn_w[gc];
+        s_par[i][KIN + 4] = bn_b[gc];
+    }
+    for (int i = threadIdx.x; i < C * E; i += 256) {
+        const int n = i / C, c = i - n * C;                         // coalesced read of W1 [E][C]
+        s_w1[c][n] = W1[(size_t)g * E * C + i];
+    }
+    __syncthreads();
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    float xr[KIN];
+#pragma unroll
+    for (int k = 0; k < KIN; ++k) xr[k] = x[((size_t)g * R + r) * KIN + k];
+    float acc[E];
+#pragma unroll
+    for (int n = 0; n < E; ++n) acc[n] = b1[(size_t)g * E + n];
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) {
+        const float4 p0 = *(const float4*)&s_par[c][0], p1 = *(const float4*)&s_par[c][4];
+        const float pv[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+        float a = pv[KIN];
+#pragma unroll
+        for (int k = 0; k < KIN; ++k) a += pv[k] * xr[k];
+        a = fmaxf(a, 0.f);
+        const float hb = (a - pv[KIN + 1]) * pv[KIN + 2] * pv[KIN + 3] + pv[KIN + 4];       // the expression of gbn_apply_kernel
+#pragma unroll
+        for (int n4 = 0; n4 < E / 4; ++n4) {
+            const float4 w = *(const float4*)&s_w1[c][4 * n4];
+            acc[4 * n4 + 0] += w.x * hb;                                                 // ascending c from the bias: glinear_fwd_kernel's order
+            acc[4 * n4 + 1] += w.y * hb;
+            acc[4 * n4 + 2] += w.z * hb;
+            acc[4 * n4 + 3] += w.w * hb;
+        }
+    }
+    float* o = out + ((size_t)g * R + r) * E;
+#pragma unroll
+    for (int n4 = 0; n4 < E / 4; ++n4) *(float4*)(o + 4 * n4) = make_float4(acc[4 * n4], acc[4 * n4 + 1], acc[4 * n4 + 2], acc[4 * n4 + 3]);
+}
+
+// ---- backward -------------------------------------------------------------------------------------------------------------------
+// Both passes: workgroup = (row chunk of BW_RPC rows, group), 4 waves x BW_RPC/4 rows each, lane = channel c.
+template <int KIN, int E>
+struct LaneState {
+    HiddenPar<KIN> p;
+    float w1c[E];              // W1[n][c] for every n
+};
+template <int KIN, int E>
+__device__ __forceinline__ void load_lane_state(LaneState<KIN, E>& st, int g, int c, const float* W0, const float* b0, const float* bn_w,
+                                                const float* bn_b, const float* mean, const float* var, const float* W1, float eps) {
+    const size_t gc = (size_t)g * C + c;
+#pragma unroll
+    for (int k = 0; k < KIN; ++k) st.p.w0[k] = W0[gc * KIN + k];
+    st.p.b0 = b0[gc];
+    st.p.mu = mean[gc];
+    st.p.rs = rsqrtf(var[gc] + eps);
+    st.p.bw = bn_w[gc];
+    st.p.bb = bn_b[gc];
+#pragma unroll
+    for (int n = 0; n < E; ++n) st.w1c[n] = W1[((size_t)g * E + n) * C + c];
+}
+// the row's x and dout as wave-uniform scalars: lanes 0..E-1 load dout[r][lane], lanes 0..KIN-1 x[r][lane]; v_readlane spreads them
+template <int KIN, int E>
+__device__ __forceinline__ void row_scalars(const float* __restrict__ xg, const float* __restrict__ dg, int r, int lane, float* xr, float* dn,
+                                            float& d_own) {
+    d_own = lane < E ? dg[(size_t)r * E + lane] : 0.f;
+    const float x_own = lane < KIN ? xg[(size_t)r * KIN + lane] : 0.f;
+#pragma unroll
+    for (int k = 0; k < KIN; ++k) xr[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x_own), k));
+#pragma unroll
+    for (int n = 0; n < E; ++n) dn[n] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d_own), n));
+}
+
+// pass 1: per chunk  dW1[n][c] = sum_r dout[r][n] hb[r][c],  s1[c] = sum_r dhb,  s2[c] = sum_r dhb xhat,  db1[n] = sum_r dout[r][n]
+// partial layout per (g, chunk): E*C (dW1, n-major) | C (s1) | C (s2) | E (db1)
+template <int KIN, int E>
+__global__ __launch_bounds__(256) void gmlp_bwd_sums_kernel(const float* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ W0,
+                                                            const float* __restrict__ b0, const float* __restrict__ bn_w,
+                                                            const float* __restrict__ bn_b, const float* __restrict__ mean,
+                                                            const float* __restrict__ var, const float* __restrict__ W1, float* __restrict__ part,
+                                                            int R, float eps) {
+    __shared__ float red[4][E + 3][C];
+    const int g = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    LaneState<KIN, E> st;
+    load_lane_state<KIN, E>(st, g, lane, W0, b0, bn_w, bn_b, mean, var, W1, eps);
+    const float* xg = x + (size_t)g * R * KIN;
+    const float* dg = dout + (size_t)g * R * E;
+    const int r0 = chunk * BW_RPC + wave * (BW_RPC / 4), r1 = min(R, r0 + BW_RPC / 4);
+    float dw1[E], s1 = 0.f, s2 = 0.f, db1 = 0.f;
+#pragma unroll
+    for (int n = 0; n < E; ++n) dw1[n] = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        float xr[KIN], dn[E], d_own;
+        row_scalars<KIN, E>(xg, dg, r, lane, xr, dn, d_own);
+        const float a = fmaxf(pre_act<KIN>(st.p, xr), 0.f);
+        const float xhat = (a - st.p.mu) * st.p.rs;
+        const float hb = xhat * st.p.bw + st.p.bb;
+        float dhb = 0.f;
+#pragma unroll
+        for (int n = 0; n < E; ++n) {
+            dhb += dn[n] * st.w1c[n];                          // ascending n: glinear_bwd_dx_kernel's order
+            dw1[n] += dn[n] * hb;
+        }
+        s1 += dhb;
+        s2 += dhb * xhat;
+        db1 += d_own;
+    }
+#pragma unroll
+    for (int n = 0; n < E; ++n) red[wave][n][lane] = dw1[n];
+    red[wave][E][lane] = s1;
+    red[wave][E + 1][lane] = s2;
+    red[wave][E + 2][lane] = db1;
+    __syncthreads();
+    float* o = part + ((size_t)g * nchunk + chunk) * (E * C + 2 * C + E);
+    for (int i = threadIdx.x; i < (E + 3) * C; i += 256) {
+        const int q = i / C, c = i - q * C;
+        const float v = (red[0][q][c] + red[1][q][c]) + (red[2][q][c] + red[3][q][c]);
+        if (q < E + 2) o[i] = v;                               // dW1 rows, s1, s2 keep the [q][c] layout
+        else if (c < E) o[(E + 2) * C + c] = v;                // db1: lanes 0..E-1 carry it
+    }
+}
+// chunks added in order, each block of the sum written where it belongs: dW1 [G][E][C] | d(bn bias) = s1 [G][C] | d(bn weight) = s2 [G][C] | db1 [G][E]
+template <int E>
+__global__ __launch_bounds__(256) void gmlp_bwd_sums_final_kernel(const float* __restrict__ part, float* __restrict__ dW1, float* __restrict__ dbn_b,
+                                                                  float* __restrict__ dbn_w, float* __restrict__ db1, int nchunk) {
+    constexpr int D = E * C + 2 * C + E;
+    const int g = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= D) return;
+    float a = 0.f;
+    for (int k = 0; k < nchunk; ++k) a += part[((size_t)g * nchunk + k) * D + i];
+    if (i < E * C) dW1[(size_t)g * E * C + i] = a;
+    else if (i < E * C + C) dbn_b[(size_t)g * C + (i - E * C)] = a;
+    else if (i < E * C + 2 * C) dbn_w[(size_t)g * C + (i - E * C - C)] = a;
+    else db1[(size_t)g * E + (i - E * C - 2 * C)] = a;
+}
+template <int KIN>
+__global__ __launch_bounds__(256) void gmlp_bwd_dx_final_kernel(const float* __restrict__ part, float* __restrict__ dW0, float* __restrict__ db0, int nchunk) {
+    constexpr int D = C * KIN + C;
+    const int g = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= D) return;
+    float a = 0.f;
+    for (int k = 0; k < nchunk; ++k) a += part[((size_t)g * nchunk + k) * D + i];
+    if (i < C * KIN) dW0[(size_t)g * C * KIN + i] = a;
+    else db0[(size_t)g * C + (i - C * KIN)] = a;
+}
+
+// pass 2: dpre = relu'(a) BN'(dhb);  dx[r][k] = sum_c dpre W0[c][k] (wave reduction);  per chunk  dW0[c][k] = sum_r dpre x[r][k],  db0[c] = sum_r dpre
+// s1 / s2 [G][C]: the finished BatchNorm sums of pass 1 (= the gradients of its bias / weight).  partial layout per (g, chunk): C*KIN (dW0) | C (db0)
+template <int KIN, int E>
+__global__ __launch_bounds__(256) void gmlp_bwd_dx_kernel(const float* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ W0,
+                                                          const float* __restrict__ b0, const float* __restrict__ bn_w, const float* __restrict__ bn_b,
+                                                          const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ W1,
+                                                          const float* __restrict__ s1g, const float* __restrict__ s2g, float* __restrict__ dx,
+                                                          float* __restrict__ part, int R, float eps, int batch_stats) {
+    __shared__ float red[4][KIN + 1][C];
+    const int g = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    LaneState<KIN, E> st;
+    load_lane_state<KIN, E>(st, g, lane, W0, b0, bn_w, bn_b, mean, var, W1, eps);
+    const float s1 = s1g[(size_t)g * C + lane], s2 = s2g[(size_t)g * C + lane];
+    const float* xg = x + (size_t)g * R * KIN;
+    const float* dg = dout + (size_t)g * R * E;
+    float* dxg = dx ? dx + (size_t)g * R * KIN : nullptr;
+    const int r0 = chunk * BW_RPC + wave * (BW_RPC / 4), r1 = min(R, r0 + BW_RPC / 4);
+    float dw0[KIN], db0 = 0.f;
+#pragma unroll
+    for (int k = 0; k < KIN; ++k) dw0[k] = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        float xr[KIN], dn[E], d_own;
+        row_scalars<KIN, E>(xg, dg, r, lane, xr, dn, d_own);
+        const float pre = pre_act<KIN>(st.p, xr);
+        const float a = fmaxf(pre, 0.f);
+        float dhb = 0.f;
+#pragma unroll
+        for (int n = 0; n < E; ++n) dhb += dn[n] * st.w1c[n];
+        float v = dhb;
+        if (batch_stats) v -= s1 / (float)R + (a - st.p.mu) * st.p.rs * s2 / (float)R;      // the expression of gbn_bwd_dx_kernel
+        const float da = st.p.bw * st.p.rs * v;
+        const float dpre = a > 0.f ? da : 0.f;
+        db0 += dpre;
+        float dxk[KIN];
+#pragma unroll
+        for (int k = 0; k < KIN; ++k) {
+            dw0[k] += dpre * xr[k];
+            dxk[k] = wave_sum(dpre * st.p.w0[k]);
+        }
+        if (dxg && lane < KIN) {
+            float mine = dxk[0];
+#pragma unroll
+            for (int k = 1; k < KIN; ++k) mine = lane == k ? dxk[k] : mine;
+            dxg[(size_t)r * KIN + lane] = mine;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KIN; ++k) red[wave][k][lane] = dw0[k];
+    red[wave][KIN][lane] = db0;
+    __syncthreads();
+    float* o = part + ((size_t)g * nchunk + chunk) * (C * KIN + C);
+    for (int i = threadIdx.x; i < (KIN + 1) * C; i += 256) {
+        const int q = i / C, c = i - q * C;
+        const float v = (red[0][q][c] + red[1][q][c]) + (red[2][q][c] + red[3][q][c]);
+        if (q < KIN) o[c * KIN + q] = v;                       // dW0 [C][KIN]
+        else o[C * KIN + c] = v;                               // db0
+    }
+}
+
+bool gmlp_shape_ok(int KIN, int Cc, int E) { return KIN == 2 && Cc == C && E == 24; }
+
+}  // namespace
+
+extern "C" int medp_gmlp_supported(int KIN, int Ch, int E) { return gmlp_shape_ok(KIN, Ch, E) ? 1 : 0; }
+
+extern "C" size_t medp_gmlp_workspace_bytes(int G, int R, int KIN, int Ch, int E) {
+    if (G <= 0 || R <= 0 || !gmlp_shape_ok(KIN, Ch, E)) return 0;
+    const size_t fwd = (size_t)G * st_chunks(R) * 2 * C;
+    const size_t bwd = (size_t)G * bw_chunks(R) * ((size_t)E * C + 2 * C + E) + (size_t)G * bw_chunks(R) * ((size_t)C * KIN + C);
+    return (fwd > bwd ? fwd : bwd) * sizeof(float);
+}
+
+extern "C" int medp_gmlp_fwd(const float* x, const float* W0, const float* b0, const float* bn_w, const float* bn_b, float* running_mean,
+                             float* running_var, const float* W1, const float* b1, float* out, float* save_mean, float* save_var, int G, int R,
+                             int KIN, int Ch, int E, float eps, float momentum, int batch_stats, float* workspace, void* stream) {
+    MEDP_CHECK_ARG(x && W0 && b0 && bn_w && bn_b && W1 && b1 && out && save_mean && save_var && G > 0 && R > 0, "gmlp_fwd: bad argument");
+    if (!gmlp_shape_ok(KIN, Ch, E)) return -2;
+    MEDP_CHECK_ARG(G <= 65535, "gmlp_fwd: at most 65535 groups");
+    hipStream_t s = (hipStream_t)stream;
+    if (batch_stats) {
+        MEDP_CHECK_ARG(workspace, "gmlp_fwd: batch statistics need a workspace (medp_gmlp_workspace_bytes)");
+        const int nc = st_chunks(R);
+        gmlp_stats_partial_kernel<2><<<dim3(nc, G), 256, 0, s>>>(x, W0, b0, workspace, R);
+        gmlp_stats_final_kernel<2><<<(G * C + 255) / 256, 256, 0, s>>>(x, W0, b0, workspace, save_mean, save_var, running_mean, running_var, G, R, nc,
+                                                                         momentum);
+        MEDP_LAUNCH_CHECK("medp_gmlp_fwd(stats)");
+    } else {
+        MEDP_CHECK_ARG(running_mean && running_var, "gmlp_fwd: eval mode needs running statistics");
+        hipMemcpyAsync(save_mean, running_mean, (size_t)G * C * 4, hipMemcpyDeviceToDevice, s);
+        hipMemcpyAsync(save_var, running_var, (size_t)G * C * 4, hipMemcpyDeviceToDevice, s);
+    }
+    gmlp_out_kernel<2, 24><<<dim3((R + 255) / 256, G), 256, 0, s>>>(x, W0, b0, bn_w, bn_b, save_mean, save_var, W1, b1, out, R, eps);
+    MEDP_LAUNCH_CHECK("medp_gmlp_fwd(out)");
+    return 0;
+}
+
+extern "C" int medp_gmlp_bwd(const float* dout, const float* x, const float* W0, const float* b0, const float* bn_w, const float* bn_b,
+                             const float* save_mean, const float* save_var, const float* W1, float* dx, float* dW0, float* db0, float* dbn_w,
+                             float* dbn_b, float* dW1, float* db1, int G, int R, int KIN, int Ch, int E, float eps, int batch_stats,
+                             float* workspace, void* stream) {
+    MEDP_CHECK_ARG(dout && x && W0 && b0 && bn_w && bn_b && save_mean && save_var && W1 && dW0 && db0 && dbn_w && dbn_b && dW1 && db1 &&
+                       workspace && G > 0 && R > 0, "gmlp_bwd: bad argument");
+    if (!gmlp_shape_ok(KIN, Ch, E)) return -2;
+    MEDP_CHECK_ARG(G <= 65535, "gmlp_bwd: at most 65535 groups");
+    hipStream_t s = (hipStream_t)stream;
+    const int nc = bw_chunks(R);
+    const int D1 = E * C + 2 * C + E, D0 = C * KIN + C;
+    float* part1 = workspace;
+    float* part0 = part1 + (size_t)G * nc * D1;
+    gmlp_bwd_sums_kernel<2, 24><<<dim3(nc, G), 256, 0, s>>>(dout, x, W0, b0, bn_w, bn_b, save_mean, save_var, W1, part1, R, eps);
+    gmlp_bwd_sums_final_kernel<24><<<dim3((D1 + 255) / 256, G), 256, 0, s>>>(part1, dW1, dbn_b, dbn_w, db1, nc);
+    MEDP_LAUNCH_CHECK("medp_gmlp_bwd(sums)");
+    gmlp_bwd_dx_kernel<2, 24><<<dim3(nc, G), 256, 0, s>>>(dout, x, W0, b0, bn_w, bn_b, save_mean, save_var, W1, dbn_b, dbn_w, dx, part0, R, eps,
+                                                          batch_stats);
+    gmlp_bwd_dx_final_kernel<2><<<dim3((D0 + 255) / 256, G), 256, 0, s>>>(part0, dW0, db0, nc);
+    MEDP_LAUNCH_CHECK("medp_gmlp_bwd(dx)");
+    return 0;
+}

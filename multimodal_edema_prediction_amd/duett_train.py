@@ -91,6 +91,44 @@ class GBatchNormFn(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
+class GroupMlpFn(torch.autograd.Function):
+    """Linear(KIN, C) -> ReLU -> BatchNorm(C) -> Linear(C, E) of every group (variable) as fused kernels that recompute the hidden row
+    instead of storing it (csrc/duett_embed_train.hip): x [G,R,KIN] -> [G,R,E].  Replaces GLinearFn -> ActFn -> GBatchNormFn -> GLinearFn
+    (7 forward and ~20 backward launches over two 75-MB activations at cfg3) by 3 + 4 launches over x and dout."""
+
+    @staticmethod
+    def forward(ctx, x, W0, b0, bn_w, bn_b, rmean, rvar, W1, b1, batch_stats):
+        x, W0, b0, bn_w, bn_b, W1, b1 = (t.contiguous() for t in (x, W0, b0, bn_w, bn_b, W1, b1))
+        G, R, KIN = x.shape
+        Ch, E = W0.shape[1], W1.shape[1]
+        out = torch.empty((G, R, E), dtype=F32, device=x.device)
+        sm = torch.empty((G, Ch), dtype=F32, device=x.device)
+        sv = torch.empty((G, Ch), dtype=F32, device=x.device)
+        ws = torch.empty(lib().medp_gmlp_workspace_bytes(G, R, KIN, Ch, E) // 4, dtype=F32, device=x.device)
+        check(lib().medp_gmlp_fwd(ptr(x), ptr(W0), ptr(b0), ptr(bn_w), ptr(bn_b), ptr(rmean), ptr(rvar), ptr(W1), ptr(b1), ptr(out), ptr(sm),
+                                  ptr(sv), G, R, KIN, Ch, E, BN_EPS, BN_MOMENTUM, int(batch_stats), ptr(ws), stream()), "gmlp_fwd")
+        ctx.save_for_backward(x, W0, b0, bn_w, bn_b, sm, sv, W1)
+        ctx.batch_stats = batch_stats
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, W0, b0, bn_w, bn_b, sm, sv, W1 = ctx.saved_tensors
+        G, R, KIN = x.shape
+        Ch, E = W0.shape[1], W1.shape[1]
+        d = dout.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW0, db0, dbw, dbb = torch.empty_like(W0), torch.empty_like(b0), torch.empty_like(bn_w), torch.empty_like(bn_b)
+        dW1, db1 = torch.empty_like(W1), torch.empty((G, E), dtype=F32, device=x.device)
+        ws = torch.empty(lib().medp_gmlp_workspace_bytes(G, R, KIN, Ch, E) // 4, dtype=F32, device=x.device)
+        check(lib().medp_gmlp_bwd(ptr(d), ptr(x), ptr(W0), ptr(b0), ptr(bn_w), ptr(bn_b), ptr(sm), ptr(sv), ptr(W1), ptr(dx), ptr(dW0), ptr(db0),
+                                  ptr(dbw), ptr(dbb), ptr(dW1), ptr(db1), G, R, KIN, Ch, E, BN_EPS, int(ctx.batch_stats), ptr(ws), stream()), "gmlp_bwd")
+        return dx, dW0, db0, dbw, dbb, None, None, dW1, db1, None
+
+
+_FUSED_GMLP = __import__("os").environ.get("MEDP_DUETT_FUSED_GMLP", "1") == "1"
+
+
 class EmbedInputsFn(torch.autograd.Function):
     """(value, n_obs_embedding[clip(int(count))]) per variable: xs_feats [B,T,2V+1], table [16,1] -> [V, B*T, 2]"""
 
@@ -422,6 +460,9 @@ def _bind_stacked_bn(model):
 
 
 def _mlp_bn(x, lin0_w, lin0_b, bn_w, bn_b, rm, rv, lin1_w, lin1_b, act_mode, batch_stats):
+    if (_FUSED_GMLP and lin1_w is not None and act_mode == 0
+            and lib().medp_gmlp_supported(x.shape[-1], lin0_w.shape[1], lin1_w.shape[1]) == 1):
+        return GroupMlpFn.apply(x, lin0_w, lin0_b, bn_w, bn_b, rm, rv, lin1_w, lin1_b, batch_stats)
     h = GLinearFn.apply(x, lin0_w, lin0_b)
     a = ActFn.apply(h, act_mode)
     hb = GBatchNormFn.apply(a, bn_w, bn_b, rm, rv, batch_stats)
