@@ -15,7 +15,7 @@ namespace {
 
 constexpr int C = 64;          // hidden width = lanes of a wave
 constexpr int ST_RPC = 128;    // rows per workgroup of the statistics pass (same chunking as gbn_stats_partial_kernel)
-constexpr int BW_RPC = 512;    // rows per workgroup of the two backward passes (4 waves x 128 rows)
+constexpr int BW_RPC = 256;    // rows per workgroup of the two backward passes (4 waves x 64 rows, staged in LDS)
 inline int st_chunks(int R) { return (R + ST_RPC - 1) / ST_RPC; }
 inline int bw_chunks(int R) { return (R + BW_RPC - 1) / BW_RPC; }
 
@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256) void gmlp_stats_final_kernel(const float* __re
     p.b0 = b0[i];
     const float pivot = fmaxf(pre_act<KIN>(p, x + (size_t)g * R * KIN), 0.f);
     float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
     for (int k = 0; k < nchunk; ++k) {
         const float* o = part + (((size_t)g * nchunk + k) * 2) * C;
         s1 += o[c];
@@ -90,18 +91,21 @@ __global__ __launch_bounds__(256) void gmlp_stats_final_kernel(const float* __re
     }
 }
 
-// ---- forward, pass 2: out[r][:] = b1 + W1 BN(relu(W0 x[r] + b0)); a thread owns a row and its E accumulators, the group's parameters
-// are broadcast out of LDS (one 16-byte read serves the wave) ------------------------------------------------------------------------
+// ---- forward, pass 2: out[r][:] = b1 + W1 BN(relu(W0 x[r] + b0)).  The group's parameters are broadcast out of LDS; a broadcast read
+// costs the LDS its full 8 clocks per 16 bytes and lane, so a thread owns OUT_RPT rows and every read feeds that many rows (one row per
+// thread was LDS-bound: 30 us at cfg3) ---------------------------------------------------------------------------------------------
+constexpr int OUT_RPT = 4, OUT_THREADS = 64;
 template <int KIN, int E>
-__global__ __launch_bounds__(256) void gmlp_out_kernel(const float* __restrict__ x, const float* __restrict__ W0, const float* __restrict__ b0,
-                                                       const float* __restrict__ bn_w, const float* __restrict__ bn_b, const float* __restrict__ mean,
-                                                       const float* __restrict__ var, const float* __restrict__ W1, const float* __restrict__ b1,
-                                                       float* __restrict__ out, int R, float eps) {
+__global__ __launch_bounds__(OUT_THREADS) void gmlp_out_kernel(const float* __restrict__ x, const float* __restrict__ W0, const float* __restrict__ b0,
+                                                               const float* __restrict__ bn_w, const float* __restrict__ bn_b,
+                                                               const float* __restrict__ mean, const float* __restrict__ var,
+                                                               const float* __restrict__ W1, const float* __restrict__ b1, float* __restrict__ out,
+                                                               int R, float eps) {
     static_assert(E % 4 == 0 && KIN <= 3, "layout");
     __shared__ __attribute__((aligned(16))) float s_par[C][8];      // w0[KIN] | b0 | mu | rs | w | b  (KIN + 5 <= 8)
     __shared__ __attribute__((aligned(16))) float s_w1[C][E];       // W1 transposed: [c][n]
     const int g = blockIdx.y;
-    for (int i = threadIdx.x; i < C; i += 256) {
+    for (int i = threadIdx.x; i < C; i += OUT_THREADS) {
         const size_t gc = (size_t)g * C + i;
 #pragma unroll
         for (int k = 0; k < KIN; ++k) s_par[i][k] = W0[gc * KIN + k];
@@ -111,40 +115,57 @@ __global__ __launch_bounds__(256) void gmlp_out_kernel(const float* __restrict__
         s_par[i][KIN + 3] = bn_w[gc];
         s_par[i][KIN + 4] = bn_b[gc];
     }
-    for (int i = threadIdx.x; i < C * E; i += 256) {
+    for (int i = threadIdx.x; i < C * E; i += OUT_THREADS) {
         const int n = i / C, c = i - n * C;                         // coalesced read of W1 [E][C]
         s_w1[c][n] = W1[(size_t)g * E * C + i];
     }
     __syncthreads();
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= R) return;
-    float xr[KIN];
+    // rows of this thread: blockIdx.x * (OUT_THREADS * OUT_RPT) + j * OUT_THREADS + threadIdx.x  (consecutive lanes = consecutive rows)
+    const int rb = blockIdx.x * (OUT_THREADS * OUT_RPT) + threadIdx.x;
+    float xr[OUT_RPT][KIN], acc[OUT_RPT][E];
 #pragma unroll
-    for (int k = 0; k < KIN; ++k) xr[k] = x[((size_t)g * R + r) * KIN + k];
-    float acc[E];
+    for (int j = 0; j < OUT_RPT; ++j) {
+        const int r = min(rb + j * OUT_THREADS, R - 1);
 #pragma unroll
-    for (int n = 0; n < E; ++n) acc[n] = b1[(size_t)g * E + n];
-#pragma unroll 4
+        for (int k = 0; k < KIN; ++k) xr[j][k] = x[((size_t)g * R + r) * KIN + k];
+#pragma unroll
+        for (int n = 0; n < E; ++n) acc[j][n] = b1[(size_t)g * E + n];
+    }
+#pragma unroll 2
     for (int c = 0; c < C; ++c) {
         const float4 p0 = *(const float4*)&s_par[c][0], p1 = *(const float4*)&s_par[c][4];
         const float pv[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
-        float a = pv[KIN];
+        float hb[OUT_RPT];
 #pragma unroll
-        for (int k = 0; k < KIN; ++k) a += pv[k] * xr[k];
-        a = fmaxf(a, 0.f);
-        const float hb = (a - pv[KIN + 1]) * pv[KIN + 2] * pv[KIN + 3] + pv[KIN + 4];       // the expression of gbn_apply_kernel
+        for (int j = 0; j < OUT_RPT; ++j) {
+            float a = pv[KIN];
+#pragma unroll
+            for (int k = 0; k < KIN; ++k) a += pv[k] * xr[j][k];
+            a = fmaxf(a, 0.f);
+            hb[j] = (a - pv[KIN + 1]) * pv[KIN + 2] * pv[KIN + 3] + pv[KIN + 4];            // the expression of gbn_apply_kernel
+        }
 #pragma unroll
         for (int n4 = 0; n4 < E / 4; ++n4) {
             const float4 w = *(const float4*)&s_w1[c][4 * n4];
-            acc[4 * n4 + 0] += w.x * hb;                                                 // ascending c from the bias: glinear_fwd_kernel's order
-            acc[4 * n4 + 1] += w.y * hb;
-            acc[4 * n4 + 2] += w.z * hb;
-            acc[4 * n4 + 3] += w.w * hb;
+#pragma unroll
+            for (int j = 0; j < OUT_RPT; ++j) {
+                acc[j][4 * n4 + 0] += w.x * hb[j];                                          // ascending c from the bias: glinear_fwd_kernel's order
+                acc[j][4 * n4 + 1] += w.y * hb[j];
+                acc[j][4 * n4 + 2] += w.z * hb[j];
+                acc[j][4 * n4 + 3] += w.w * hb[j];
+            }
         }
     }
-    float* o = out + ((size_t)g * R + r) * E;
 #pragma unroll
-    for (int n4 = 0; n4 < E / 4; ++n4) *(float4*)(o + 4 * n4) = make_float4(acc[4 * n4], acc[4 * n4 + 1], acc[4 * n4 + 2], acc[4 * n4 + 3]);
+    for (int j = 0; j < OUT_RPT; ++j) {
+        const int r = rb + j * OUT_THREADS;
+        if (r < R) {
+            float* o = out + ((size_t)g * R + r) * E;
+#pragma unroll
+            for (int n4 = 0; n4 < E / 4; ++n4)
+                *(float4*)(o + 4 * n4) = make_float4(acc[j][4 * n4], acc[j][4 * n4 + 1], acc[j][4 * n4 + 2], acc[j][4 * n4 + 3]);
+        }
+    }
 }
 
 // ---- backward -------------------------------------------------------------------------------------------------------------------
@@ -168,16 +189,44 @@ __device__ __forceinline__ void load_lane_state(LaneState<KIN, E>& st, int g, in
 #pragma unroll
     for (int n = 0; n < E; ++n) st.w1c[n] = W1[((size_t)g * E + n) * C + c];
 }
-// the row's x and dout as wave-uniform scalars: lanes 0..E-1 load dout[r][lane], lanes 0..KIN-1 x[r][lane]; v_readlane spreads them
+// The chunk's dout and x rows are staged in LDS once (coalesced 16-byte loads, all in flight together); the row loop then reads a row's
+// E + KIN values with wave-uniform addresses (LDS broadcast, in-order returns the compiler can pipeline).  Reading them per row from
+// global or scalar memory made the loop a chain of exposed load latencies (82 / 106 us per pass at cfg3).
 template <int KIN, int E>
-__device__ __forceinline__ void row_scalars(const float* __restrict__ xg, const float* __restrict__ dg, int r, int lane, float* xr, float* dn,
-                                            float& d_own) {
-    d_own = lane < E ? dg[(size_t)r * E + lane] : 0.f;
-    const float x_own = lane < KIN ? xg[(size_t)r * KIN + lane] : 0.f;
+struct RowStage {
+    static constexpr int ROWF = E + 4;                         // dout[E] | x[KIN] | pad: 16-byte aligned rows
+    static_assert(E % 4 == 0 && KIN <= 4, "row layout");
+    __device__ static __forceinline__ void fill(float* stage, const float* __restrict__ dg, const float* __restrict__ xg, int rbase, int nr) {
+        for (int i = threadIdx.x; i < nr * (E / 4); i += 256) {
+            const int row = i / (E / 4), q = i - row * (E / 4);
+            *(float4*)(stage + row * ROWF + 4 * q) = *(const float4*)(dg + ((size_t)rbase + row) * E + 4 * q);
+        }
+        for (int i = threadIdx.x; i < nr * KIN; i += 256) stage[(i / KIN) * ROWF + E + i % KIN] = xg[(size_t)rbase * KIN + i];
+    }
+    __device__ static __forceinline__ void row(const float* stage, int rl, float* xr, float* dn) {
+        const float* p = stage + rl * ROWF;
 #pragma unroll
-    for (int k = 0; k < KIN; ++k) xr[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x_own), k));
+        for (int q = 0; q < E / 4; ++q) {
+            const float4 v = *(const float4*)(p + 4 * q);
+            dn[4 * q] = v.x; dn[4 * q + 1] = v.y; dn[4 * q + 2] = v.z; dn[4 * q + 3] = v.w;
+        }
+        const float4 xv = *(const float4*)(p + E);
+        const float xa[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
-    for (int n = 0; n < E; ++n) dn[n] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d_own), n));
+        for (int k = 0; k < KIN; ++k) xr[k] = xa[k];
+    }
+};
+// sum over the 64 lanes in a fixed order: DPP butterfly inside each 16-lane row (VALU rate, no LDS round trips), then the four rows
+__device__ __forceinline__ float wave_sum_dpp(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));    // row_half_mirror
+    x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));    // row_mirror
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 // pass 1: per chunk  dW1[n][c] = sum_r dout[r][n] hb[r][c],  s1[c] = sum_r dhb,  s2[c] = sum_r dhb xhat,  db1[n] = sum_r dout[r][n]
@@ -188,20 +237,27 @@ __global__ __launch_bounds__(256) void gmlp_bwd_sums_kernel(const float* __restr
                                                             const float* __restrict__ bn_b, const float* __restrict__ mean,
                                                             const float* __restrict__ var, const float* __restrict__ W1, float* __restrict__ part,
                                                             int R, float eps) {
-    __shared__ float red[4][E + 3][C];
+    using RS = RowStage<KIN, E>;
+    constexpr int RED_F = 4 * (E + 3) * C, STAGE_F = BW_RPC * RS::ROWF;
+    __shared__ __attribute__((aligned(16))) float smem[RED_F > STAGE_F ? RED_F : STAGE_F];          // the staged rows, then the cross-wave sums
+    float (*red)[E + 3][C] = (float (*)[E + 3][C])smem;
     const int g = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     LaneState<KIN, E> st;
     load_lane_state<KIN, E>(st, g, lane, W0, b0, bn_w, bn_b, mean, var, W1, eps);
-    const float* xg = x + (size_t)g * R * KIN;
-    const float* dg = dout + (size_t)g * R * E;
-    const int r0 = chunk * BW_RPC + wave * (BW_RPC / 4), r1 = min(R, r0 + BW_RPC / 4);
+    const int rbase = chunk * BW_RPC, nr = min(R - rbase, BW_RPC);
+    RS::fill(smem, dout + (size_t)g * R * E, x + (size_t)g * R * KIN, rbase, nr);
+    __syncthreads();
+    const int l0 = wave * (BW_RPC / 4), l1 = min(nr, l0 + BW_RPC / 4);
     float dw1[E], s1 = 0.f, s2 = 0.f, db1 = 0.f;
 #pragma unroll
     for (int n = 0; n < E; ++n) dw1[n] = 0.f;
-    for (int r = r0; r < r1; ++r) {
-        float xr[KIN], dn[E], d_own;
-        row_scalars<KIN, E>(xg, dg, r, lane, xr, dn, d_own);
+    if (lane < E)                                              // db1: lane n adds column n of the wave's rows
+        for (int rl = l0; rl < l1; ++rl) db1 += smem[rl * RS::ROWF + lane];
+#pragma unroll 2
+    for (int rl = l0; rl < l1; ++rl) {
+        float xr[KIN], dn[E];
+        RS::row(smem, rl, xr, dn);
         const float a = fmaxf(pre_act<KIN>(st.p, xr), 0.f);
         const float xhat = (a - st.p.mu) * st.p.rs;
         const float hb = xhat * st.p.bw + st.p.bb;
@@ -213,8 +269,8 @@ __global__ __launch_bounds__(256) void gmlp_bwd_sums_kernel(const float* __restr
         }
         s1 += dhb;
         s2 += dhb * xhat;
-        db1 += d_own;
     }
+    __syncthreads();                                           // every wave is done with the staged rows: their LDS becomes `red`
 #pragma unroll
     for (int n = 0; n < E; ++n) red[wave][n][lane] = dw1[n];
     red[wave][E][lane] = s1;
@@ -238,6 +294,7 @@ __global__ __launch_bounds__(256) void gmlp_bwd_sums_final_kernel(const float* _
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= D) return;
     float a = 0.f;
+#pragma unroll 8
     for (int k = 0; k < nchunk; ++k) a += part[((size_t)g * nchunk + k) * D + i];
     if (i < E * C) dW1[(size_t)g * E * C + i] = a;
     else if (i < E * C + C) dbn_b[(size_t)g * C + (i - E * C)] = a;
@@ -251,6 +308,7 @@ __global__ __launch_bounds__(256) void gmlp_bwd_dx_final_kernel(const float* __r
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= D) return;
     float a = 0.f;
+#pragma unroll 8
     for (int k = 0; k < nchunk; ++k) a += part[((size_t)g * nchunk + k) * D + i];
     if (i < C * KIN) dW0[(size_t)g * C * KIN + i] = a;
     else db0[(size_t)g * C + (i - C * KIN)] = a;
@@ -264,22 +322,26 @@ __global__ __launch_bounds__(256) void gmlp_bwd_dx_kernel(const float* __restric
                                                           const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ W1,
                                                           const float* __restrict__ s1g, const float* __restrict__ s2g, float* __restrict__ dx,
                                                           float* __restrict__ part, int R, float eps, int batch_stats) {
+    using RS = RowStage<KIN, E>;
+    __shared__ __attribute__((aligned(16))) float stage[BW_RPC * RS::ROWF];
     __shared__ float red[4][KIN + 1][C];
+    __shared__ float sdx[BW_RPC][KIN];                          // dx of the chunk's rows, written out coalesced at the end
     const int g = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     LaneState<KIN, E> st;
     load_lane_state<KIN, E>(st, g, lane, W0, b0, bn_w, bn_b, mean, var, W1, eps);
     const float s1 = s1g[(size_t)g * C + lane], s2 = s2g[(size_t)g * C + lane];
-    const float* xg = x + (size_t)g * R * KIN;
-    const float* dg = dout + (size_t)g * R * E;
-    float* dxg = dx ? dx + (size_t)g * R * KIN : nullptr;
-    const int r0 = chunk * BW_RPC + wave * (BW_RPC / 4), r1 = min(R, r0 + BW_RPC / 4);
+    const int rbase = chunk * BW_RPC, nr = min(R - rbase, BW_RPC);
+    RS::fill(stage, dout + (size_t)g * R * E, x + (size_t)g * R * KIN, rbase, nr);
+    __syncthreads();
+    const int l0 = wave * (BW_RPC / 4), l1 = min(nr, l0 + BW_RPC / 4);
     float dw0[KIN], db0 = 0.f;
 #pragma unroll
     for (int k = 0; k < KIN; ++k) dw0[k] = 0.f;
-    for (int r = r0; r < r1; ++r) {
-        float xr[KIN], dn[E], d_own;
-        row_scalars<KIN, E>(xg, dg, r, lane, xr, dn, d_own);
+#pragma unroll 2
+    for (int rl = l0; rl < l1; ++rl) {
+        float xr[KIN], dn[E];
+        RS::row(stage, rl, xr, dn);
         const float pre = pre_act<KIN>(st.p, xr);
         const float a = fmaxf(pre, 0.f);
         float dhb = 0.f;
@@ -290,23 +352,19 @@ __global__ __launch_bounds__(256) void gmlp_bwd_dx_kernel(const float* __restric
         const float da = st.p.bw * st.p.rs * v;
         const float dpre = a > 0.f ? da : 0.f;
         db0 += dpre;
-        float dxk[KIN];
 #pragma unroll
         for (int k = 0; k < KIN; ++k) {
             dw0[k] += dpre * xr[k];
-            dxk[k] = wave_sum(dpre * st.p.w0[k]);
-        }
-        if (dxg && lane < KIN) {
-            float mine = dxk[0];
-#pragma unroll
-            for (int k = 1; k < KIN; ++k) mine = lane == k ? dxk[k] : mine;
-            dxg[(size_t)r * KIN + lane] = mine;
+            const float t = wave_sum_dpp(dpre * st.p.w0[k]);
+            if (lane == k) sdx[rl][k] = t;
         }
     }
 #pragma unroll
     for (int k = 0; k < KIN; ++k) red[wave][k][lane] = dw0[k];
     red[wave][KIN][lane] = db0;
     __syncthreads();
+    if (dx)
+        for (int i = threadIdx.x; i < nr * KIN; i += 256) dx[((size_t)g * R + rbase) * KIN + i] = (&sdx[0][0])[i];
     float* o = part + ((size_t)g * nchunk + chunk) * (C * KIN + C);
     for (int i = threadIdx.x; i < (KIN + 1) * C; i += 256) {
         const int q = i / C, c = i - q * C;
@@ -348,7 +406,8 @@ extern "C" int medp_gmlp_fwd(const float* x, const float* W0, const float* b0, c
         hipMemcpyAsync(save_mean, running_mean, (size_t)G * C * 4, hipMemcpyDeviceToDevice, s);
         hipMemcpyAsync(save_var, running_var, (size_t)G * C * 4, hipMemcpyDeviceToDevice, s);
     }
-    gmlp_out_kernel<2, 24><<<dim3((R + 255) / 256, G), 256, 0, s>>>(x, W0, b0, bn_w, bn_b, save_mean, save_var, W1, b1, out, R, eps);
+    gmlp_out_kernel<2, 24><<<dim3((R + OUT_THREADS * OUT_RPT - 1) / (OUT_THREADS * OUT_RPT), G), OUT_THREADS, 0, s>>>(x, W0, b0, bn_w, bn_b, save_mean, save_var, W1, b1,
+                                                                                                                out, R, eps);
     MEDP_LAUNCH_CHECK("medp_gmlp_fwd(out)");
     return 0;
 }

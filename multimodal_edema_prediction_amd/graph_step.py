@@ -510,9 +510,10 @@ class GraphedStudentStep(_GraphedStep):
         self.z_next = None
         self._expect = None
         self.swap_roles = os.environ.get("MEDP_STUDENT_SWAP", "0") == "1"       # measured slower (9.00 vs 8.74 ms): more concurrency = more CU contention
-        # the student's branch is the long one here: the frozen teacher's persistent GEMMs hold at most 176 CUs per launch
-        # (in-box A/B: 8.70 ms at the default, 8.47 at 176 / 160, 8.99 at 128)
-        prev = lib().medp_gemm_persistent_cap(int(os.environ.get("MEDP_STUDENT_GEMM_CAP", "176")) if pipeline_teacher else 0)
+        # MEDP_STUDENT_GEMM_CAP = n: the frozen teacher's persistent GEMMs hold at most n CUs per launch.  Round 2 shipped 176 (the student's
+        # branch was the long one: 8.47 ms against 8.70 uncapped); with the fused encoder halves and embedding kernels of round 3 the training
+        # branch needs fewer CUs and the cap costs 4 % (7.02 ms at 176, 6.73-6.76 at 200 / 224 / none, profiles/r03_ab_experiments.txt): off.
+        prev = lib().medp_gemm_persistent_cap(int(os.environ.get("MEDP_STUDENT_GEMM_CAP", "0")) if pipeline_teacher else 0)
         try:
             self._setup(optimizer, device, world, group, split, pipeline_teacher, warmup, before_capture, after_capture)
         finally:
