@@ -491,7 +491,8 @@ class GraphedStudentStep(_GraphedStep):
     encoder + its own frozen DuETT + fusion head, `main_logit` only) runs beside the student's step on batch k."""
 
     def __init__(self, student, teacher, kd_loss_fn, optimizer, example_batch: dict, device, world: int = 1, group=None,
-                 warmup: int = 3, split: bool = False, before_capture=None, pipeline_teacher: bool = True, after_capture=None):
+                 warmup: int = 3, split: bool = False, before_capture=None, pipeline_teacher: bool = True, after_capture=None,
+                 swap_roles=None):
         if any(p.requires_grad for p in teacher.parameters()):
             raise ValueError("the KD teacher must be frozen (trainer.py:856-865)")
         self.student, self.teacher, self.loss_fn = student, teacher, kd_loss_fn
@@ -509,7 +510,10 @@ class GraphedStudentStep(_GraphedStep):
             self.z_cur = self._teacher_logit(self.cur).clone()
         self.z_next = None
         self._expect = None
-        self.swap_roles = os.environ.get("MEDP_STUDENT_SWAP", "0") == "1"       # measured slower (9.00 vs 8.74 ms): more concurrency = more CU contention
+        # roles swapped (see _whole_fwd_bwd): the frozen teacher on the step's own stream, where it may fork its time-series half beside its
+        # CXR encoder.  Round 2 measured this slower (9.00 vs 8.74 ms); with round 3's lighter training branch it is 3.7 % faster (6.46 vs
+        # 6.70 ms, profiles/r03_ab_experiments.txt): default on, MEDP_STUDENT_SWAP=0 / swap_roles=False for the two-branch form.
+        self.swap_roles = (os.environ.get("MEDP_STUDENT_SWAP", "1") == "1") if swap_roles is None else bool(swap_roles)
         # MEDP_STUDENT_GEMM_CAP = n: the frozen teacher's persistent GEMMs hold at most n CUs per launch.  Round 2 shipped 176 (the student's
         # branch was the long one: 8.47 ms against 8.70 uncapped); with the fused encoder halves and embedding kernels of round 3 the training
         # branch needs fewer CUs and the cap costs 4 % (7.02 ms at 176, 6.73-6.76 at 200 / 224 / none, profiles/r03_ab_experiments.txt): off.

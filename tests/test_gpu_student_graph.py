@@ -66,8 +66,12 @@ def test_graphed_student_step_equals_eager_engine_step():
             assert p.grad is None and len(og.state.get(p, {})) == 0, k
 
 
+@pytest.mark.parametrize("swap", [True, False])
 @pytest.mark.parametrize("split", [False, True])
-def test_teacher_one_batch_ahead_is_bit_identical(split):
+def test_teacher_one_batch_ahead_is_bit_identical(split, swap):
+    """pipeline_teacher: the frozen teacher's forward for batch k+1 beside the student's step on batch k — as the forked branch
+    (swap_roles=False) or on the step's own stream with the student's step forked (swap_roles=True, the default: the teacher may then
+    fork its time-series half beside its CXR encoder).  Same losses, parameters and buffers as the unpipelined graph."""
     from multimodal_edema_prediction_amd.graph_step import GraphedStudentStep
     from multimodal_edema_prediction_amd.losses_duett import StudentKDLoss
     from multimodal_edema_prediction_amd.optim import FusedAdamW
@@ -80,7 +84,7 @@ def test_teacher_one_batch_ahead_is_bit_identical(split):
     def run(pipeline):
         s, t = _build(dev)
         opt = FusedAdamW([p for p in s.parameters() if p.requires_grad], lr=1e-3, weight_decay=5e-2)
-        gs = GraphedStudentStep(s, t, kd, opt, batches[0], dev, warmup=2, split=split, pipeline_teacher=pipeline)
+        gs = GraphedStudentStep(s, t, kd, opt, batches[0], dev, warmup=2, split=split, pipeline_teacher=pipeline, swap_roles=swap)
         losses = [float(gs.step(batches[k], batches[n])["loss"].item()) for k, n in zip(order, announce)]
         return losses, {k: p.detach().clone() for k, p in s.named_parameters()}, {k: b.detach().clone() for k, b in s.named_buffers()}
 
