@@ -400,6 +400,10 @@ int medp_psi_assemble_bwd_slices(int B, int T, int V);
 int medp_psi_assemble_bwd(const float* xs_ts, const float* dpsi, float* d_var_out, float* d_tab_partial, float* d_special_partial, int B,
                           int T, int V, int E, void* stream);
 int medp_axis_swap(const float* in, float* out, int B, int A1, int A2, int E, void* stream);
+/* the axis swap with the new leading axis' positional embedding added on the way: mode 1: add [A2][A1][E] shared by the batch (model :80-81);
+ * mode 3: add [B*(A2-1)][A1][E] per sample for a2 < A2-1 and add_last [A1][E] for the last row (model :90 without the concatenation) */
+int medp_axis_swap_add(const float* in, const float* add, const float* add_last, float* out, int B, int A1, int A2, int E, int mode,
+                       void* stream);
 int medp_add_bcast(const float* a, const float* b, float* out, long long per_batch, int B, int broadcast_b, void* stream);
 
 /* ---- LocalTrajectoryEncoder (models/main_architecture_duett.py:1242-1391) -------------------------------

@@ -140,6 +140,7 @@ SIGNATURES = {
     "medp_psi_assemble_bwd_slices": (I, [I, I, I]),
     "medp_psi_assemble_bwd": (I, [P, P, P, P, P, I, I, I, I, P]),
     "medp_axis_swap": (I, [P, P, I, I, I, I, P]),
+    "medp_axis_swap_add": (I, [P, P, P, P, I, I, I, I, I, P]),
     "medp_add_bcast": (I, [P, P, P, LL, I, I, P]),
     "medp_masked_mse": (I, [P, P, P, P, P, I, P]),
     "medp_bce_mean": (I, [P, P, P, P, P, I, P]),

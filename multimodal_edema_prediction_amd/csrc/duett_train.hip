@@ -348,6 +348,30 @@ __global__ __launch_bounds__(256) void axis_swap_kernel(const float* __restrict_
         *(float4*)(out + i * 4) = *(const float4*)(in + ((((size_t)b * A1 + a1) * A2 + a2) * E4 + e4) * 4);
     }
 }
+// the swap with the positional embedding of the new leading axis added on the way (model :80-81, :90): out[b][a2][a1][:] = in[b][a1][a2][:] + emb,
+//   MODE 1: emb = add[a2][a1][:]  (one table for every batch element: `full_event_embedding`)
+//   MODE 3: emb = a2 < A2 - 1 ? add[b * (A2 - 1) + a2][a1][:] : add_last[a1][:]  (the per-sample time embedding rows and the REP row — the
+//           reference concatenates them into [B, T + 1, tt] first; here that tensor is never built)
+template <int MODE>
+__global__ __launch_bounds__(256) void axis_swap_add_kernel(const float* __restrict__ in, const float* __restrict__ add, const float* __restrict__ add_last,
+                                                            float* __restrict__ out, int B, int A1, int A2, int E4) {
+    const size_t total = (size_t)B * A1 * A2 * E4;
+    const size_t row4 = (size_t)A1 * E4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int e4 = (int)(i % E4);
+        size_t r = i / E4;
+        const int a1 = (int)(r % A1);
+        r /= A1;
+        const int a2 = (int)(r % A2), b = (int)(r / A2);
+        const float4 x = *(const float4*)(in + ((((size_t)b * A1 + a1) * A2 + a2) * E4 + e4) * 4);
+        const size_t rest = (size_t)a1 * E4 + e4;
+        const float* ep;
+        if (MODE == 1) ep = add + ((size_t)a2 * row4 + rest) * 4;
+        else ep = a2 < A2 - 1 ? add + (((size_t)b * (A2 - 1) + a2) * row4 + rest) * 4 : add_last + rest * 4;
+        const float4 y = *(const float4*)ep;
+        *(float4*)(out + i * 4) = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    }
+}
 // out = a + b  (b broadcast over the leading batch dim when b_bs == 0)
 __global__ __launch_bounds__(256) void add_bcast_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t per_batch,
                                                         int B, int bcast) {
@@ -491,6 +515,16 @@ extern "C" int medp_axis_swap(const float* in, float* out, int B, int A1, int A2
     MEDP_CHECK_ARG(in && out && B > 0 && A1 > 0 && A2 > 0 && E % 4 == 0, "axis_swap: bad argument");
     axis_swap_kernel<<<grid_for((size_t)B * A1 * A2 * E / 4), 256, 0, (hipStream_t)stream>>>(in, out, B, A1, A2, E / 4);
     MEDP_LAUNCH_CHECK("medp_axis_swap");
+    return 0;
+}
+extern "C" int medp_axis_swap_add(const float* in, const float* add, const float* add_last, float* out, int B, int A1, int A2, int E, int mode,
+                                  void* stream) {
+    MEDP_CHECK_ARG(in && add && out && B > 0 && A1 > 0 && A2 > 0 && E % 4 == 0 && (mode == 1 || (mode == 3 && add_last && A2 > 1)),
+                   "axis_swap_add: bad argument");
+    const int grid = grid_for((size_t)B * A1 * A2 * E / 4);
+    if (mode == 1) axis_swap_add_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(in, add, add_last, out, B, A1, A2, E / 4);
+    else axis_swap_add_kernel<3><<<grid, 256, 0, (hipStream_t)stream>>>(in, add, add_last, out, B, A1, A2, E / 4);
+    MEDP_LAUNCH_CHECK("medp_axis_swap_add");
     return 0;
 }
 extern "C" int medp_add_bcast(const float* a, const float* b, float* out, long long per_batch, int B, int broadcast_b, void* stream) {

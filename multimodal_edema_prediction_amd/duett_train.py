@@ -225,6 +225,36 @@ class AddBcastFn(torch.autograd.Function):
         return d, db
 
 
+class SwapAddFn(torch.autograd.Function):
+    """AxisSwapFn + AddBcastFn as one pass: x [B, A1, A2, E] -> [B, A2, A1*E] + positional embedding.  `add_last is None`: `add` [A2, A1*E] is
+    shared by the batch (full_event_embedding, model :80-81).  Otherwise `add` [B, A2-1, A1*E] holds the per-sample rows and `add_last`
+    [A1*E] the last row (the time embedding and the REP embedding, model :90): the [B, T+1, tt] concatenation of the reference is not built,
+    and its backward hands the Linear behind `add` a view instead of a reduced / re-copied tensor."""
+
+    @staticmethod
+    def forward(ctx, x, add, add_last):
+        x, add = x.contiguous(), add.contiguous()
+        B, A1, A2, E = x.shape
+        y = torch.empty((B, A2, A1 * E), dtype=F32, device=x.device)
+        last = add_last.contiguous() if add_last is not None else None
+        check(lib().medp_axis_swap_add(ptr(x), ptr(add), ptr(last), ptr(y), B, A1, A2, E, 1 if last is None else 3, stream()), "axis_swap_add")
+        ctx.cfg = (B, A1, A2, E, tuple(add.shape), None if last is None else tuple(add_last.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, d):
+        B, A1, A2, E, ashape, lshape = ctx.cfg
+        d = d.contiguous()
+        dx = torch.empty((B, A1, A2, E), dtype=F32, device=d.device)
+        check(lib().medp_axis_swap(ptr(d), ptr(dx), B, A2, A1, E, stream()), "axis_swap(bwd)")
+        if lshape is None:
+            return dx, Fn.colsum(d.view(B, A2 * A1 * E)).view(ashape), None
+        d3 = d.view(B, A2, A1 * E)
+        d_add = d3[:, :A2 - 1]                                                                # a view: the per-sample rows [B, A2-1, A1*E]
+        d_last = Fn.colsum(d3[:, A2 - 1]).view(lshape)                                        # REP row: summed over the batch
+        return dx, d_add, d_last
+
+
 class ScaleNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, g, eps):
@@ -529,7 +559,9 @@ def encode_training(model, x):
     w3_p = torch.cat([tm[3].weight, tm[3].weight.new_zeros(tm[3].weight.shape[0], pad)], 1) if pad else tm[3].weight
     tt = E * (V + 1)
     temb = A.linear(hb_p, w3_p, tm[3].bias).view(B, T, tt)
-    time_emb = torch.cat([temb, model.full_rep_embedding.weight.view(1, 1, -1).expand(B, -1, -1)], 1)     # [B, T+1, tt]
+    fused_swap = __import__("os").environ.get("MEDP_DUETT_FUSED_SWAP", "1") == "1"
+    if not fused_swap:
+        time_emb = torch.cat([temb, model.full_rep_embedding.weight.view(1, 1, -1).expand(B, -1, -1)], 1)     # [B, T+1, tt]
     if bs:
         with torch.no_grad():
             nbt += 1                                      # all V per-variable counters at once (views of one stacked buffer)
@@ -538,10 +570,16 @@ def encode_training(model, x):
     seed = A.next_seed() if (model.training and model.transformer_dropout > 0) else 0
     T1, V1 = T + 1, V + 1
     for l, (ev, tv) in enumerate(zip(model.event_transformers, model.time_transformers)):
-        xe = AxisSwapFn.apply(psi).view(B, V1, T1 * E)                                               # (model :80)
-        xe = AddBcastFn.apply(xe, model.full_event_embedding.weight)
+        if fused_swap:
+            xe = SwapAddFn.apply(psi, model.full_event_embedding.weight, None)                        # (model :80-81) [B, V1, T1*E]
+        else:
+            xe = AxisSwapFn.apply(psi).view(B, V1, T1 * E)
+            xe = AddBcastFn.apply(xe, model.full_event_embedding.weight)
         xe = encoder_training(ev, xe, SCALENORM_EPS, FINAL_NORM, model.training, seed, 100 + 10 * l)    # (model :81)
-        xt = AxisSwapFn.apply(xe.view(B, V1, T1, E)).view(B, T1, V1 * E)
-        xt = AddBcastFn.apply(xt, time_emb)                                                            # (model :90)
+        if fused_swap:
+            xt = SwapAddFn.apply(xe.view(B, V1, T1, E), temb, model.full_rep_embedding.weight.view(-1))   # (model :90) [B, T1, V1*E]
+        else:
+            xt = AxisSwapFn.apply(xe.view(B, V1, T1, E)).view(B, T1, V1 * E)
+            xt = AddBcastFn.apply(xt, time_emb)
         psi = encoder_training(tv, xt, SCALENORM_EPS, FINAL_NORM, model.training, seed, 105 + 10 * l).view(B, T1, V1, E)   # (model :91)
     return psi.flatten(2)

@@ -169,3 +169,24 @@ def test_fused_encoder_halves_and_operand_pool_are_bit_identical_to_the_separate
         assert g0.keys() == g1.keys()
         for k in g0:
             assert torch.equal(g0[k], g1[k]), (fused, pool, k, float((g0[k] - g1[k]).abs().max()))
+
+
+def test_swap_with_embedding_added_on_the_way_matches_the_separate_kernels():
+    """SwapAddFn (axis swap + positional embedding in one pass, the [B, T+1, tt] time-embedding concatenation never built) against
+    AxisSwapFn -> AddBcastFn -> torch.cat: same logits bit for bit; gradients equal except where a sum over the batch changed its order."""
+    res = {}
+    for flag in ("0", "1"):
+        os.environ["MEDP_DUETT_FUSED_SWAP"] = flag
+        try:
+            res[flag] = _student_grads(0.2, fused=True, pool=False)
+        finally:
+            os.environ.pop("MEDP_DUETT_FUSED_SWAP", None)
+    (z0, g0), (z1, g1) = res["0"], res["1"]
+    assert torch.equal(z0, z1)
+    assert g0.keys() == g1.keys()
+    same = 0
+    for k in g0:
+        a, b = g0[k].double(), g1[k].double()
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-9, k
+        same += int(torch.equal(g0[k], g1[k]))
+    assert same >= len(g0) - 4, (same, len(g0))
