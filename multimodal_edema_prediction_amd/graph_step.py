@@ -80,15 +80,40 @@ class _TrainSnapshot:
                 self.opt._step = self.host_step
 
 
+# The library mixes ONE device counter into every dropout seed (medp_rng_set_epoch_ptr): the step that registered its counter last owns
+# it.  The registered tensor is held here, so the pointer never dangles after its step object is gone (an eager forward afterwards used
+# to read freed — possibly re-used — memory: masks that changed from call to call); a step that is collected while it still owns the
+# registration takes it back (NULL = no epoch, the per-call seeds alone).
+_EPOCH_OWNER = [None]
+
+
+def _register_epoch(epoch: torch.Tensor):
+    check(lib().medp_rng_set_epoch_ptr(ptr(epoch)), "rng_set_epoch_ptr")
+    _EPOCH_OWNER[0] = epoch
+
+
+def _release_epoch(epoch: torch.Tensor):
+    if _EPOCH_OWNER[0] is epoch:
+        try:
+            lib().medp_rng_set_epoch_ptr(None)
+        finally:
+            _EPOCH_OWNER[0] = None
+
+
 class _GraphedStep:
     """Capture / replay machinery common to both steps.  Subclasses provide `_frozen_forward()` (frozen part for the NEXT
     batch, on the current stream, returns nothing), `_train_fwd_bwd()` (returns the output dict) and `_hand_over()`."""
+
+    def __del__(self):
+        ep = self.__dict__.get("epoch")
+        if ep is not None:
+            _release_epoch(ep)
 
     def _setup(self, optimizer, device, world, group, split, pipeline, warmup, before_capture, after_capture=None):
         self.opt, self.device, self.world, self.group = optimizer, device, world, group
         self.pipeline = bool(pipeline)
         self.epoch = torch.zeros(1, dtype=torch.int32, device=device)
-        check(lib().medp_rng_set_epoch_ptr(ptr(self.epoch)), "rng_set_epoch_ptr")
+        _register_epoch(self.epoch)
         self.params = [p for g in optimizer.param_groups for p in g["params"] if p.requires_grad]
         self.split = bool(split) or world > 1
         self.arena = None
@@ -658,13 +683,18 @@ class GraphedProbeStep:
     the capture removes the eager step's launch gaps (110 encoder launches from one C call + ~15 head launches: 4.63 -> ~4.3 ms).
     `step(pixel_values, y_multi, y_multi_mask)` copies a batch (host or device) into the static buffers and replays."""
 
+    def __del__(self):
+        ep = self.__dict__.get("epoch")
+        if ep is not None:
+            _release_epoch(ep)
+
     def __init__(self, probe, loss_fn, optimizer, example_pixels, example_y, example_mask, device, warmup: int = 3, before_capture=None):
         self.probe, self.loss_fn, self.opt, self.device = probe, loss_fn, optimizer, device
         self.pixels = example_pixels.to(device).clone()
         self.y = example_y.to(device).float().clone()
         self.mask = example_mask.to(device).float().clone()
         self.epoch = torch.zeros(1, dtype=torch.int32, device=device)
-        check(lib().medp_rng_set_epoch_ptr(ptr(self.epoch)), "rng_set_epoch_ptr")
+        _register_epoch(self.epoch)
         snap = _TrainSnapshot([p for g in optimizer.param_groups for p in g["params"] if p.requires_grad], optimizer, [probe], self.epoch)
         s = new_stream(device)
         s.wait_stream(torch.cuda.current_stream(device))

@@ -161,3 +161,32 @@ def test_teacher_forward_raises_instead_of_crashing_on_a_nested_fork():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, ref)
+
+
+def test_dropout_epoch_registration_does_not_outlive_its_step():
+    """A captured step registers its device counter with the library (`medp_rng_set_epoch_ptr`: mixed into every dropout seed).  Once the
+    step object is gone the registration is taken back — an eager forward afterwards used to read the freed counter's memory, so its
+    dropout masks changed with whatever the allocator put there next."""
+    import gc
+    from multimodal_edema_prediction_amd import autograd_ops as A, graph_step
+    from multimodal_edema_prediction_amd.graph_step import GraphedStudentStep
+    from multimodal_edema_prediction_amd.losses_duett import StudentKDLoss
+    from multimodal_edema_prediction_amd.optim import FusedAdamW
+    dev = torch.device("cuda")
+    s, t = _build(dev, dropout=0.1)
+    opt = FusedAdamW([p for p in s.parameters() if p.requires_grad], lr=1e-3, weight_decay=5e-2)
+    batches = _batches(2)
+    gs = GraphedStudentStep(s, t, StudentKDLoss("vanilla_kl", 4.0, 0.5), opt, batches[0], dev, warmup=1)
+    gs.step(batches[1], batches[0])
+    assert graph_step._EPOCH_OWNER[0] is gs.epoch
+    torch.cuda.synchronize()
+    del gs
+    gc.collect()
+    assert graph_step._EPOCH_OWNER[0] is None
+    x = torch.randn(4096, device=dev)
+    y1 = A.gelu_dropout(x, 0.3, 7, 1).clone()
+    junk = [torch.full((1 << 20,), float(i), device=dev) for i in range(64)]       # whatever memory the dead step released gets overwritten
+    torch.cuda.synchronize()
+    y2 = A.gelu_dropout(x, 0.3, 7, 1)
+    assert torch.equal(y1, y2) and float((y1 == 0).float().mean()) > 0.2
+    del junk
