@@ -169,7 +169,7 @@ class _GraphedStep:
         # measured (MEDP_PRE_CAPTURE_STREAMS overrides).  MEDP_PHASE_CHECK=1 (bench.py sets it) MEASURES the phase the step ended up in:
         # a few steps with staged host batches against resident ones on a snapshot of everything a step writes, restored afterwards;
         # `phase_log` = (pad streams, ms lost per step to the staged copy, ms of the copy alone).
-        self._pad_streams = [new_stream(device, raw=True) for _ in range(int(os.environ.get("MEDP_PRE_CAPTURE_STREAMS", "3")))]
+        self._pad_streams = [new_stream(device, raw=True) for _ in range(int(os.environ.get("MEDP_PRE_CAPTURE_STREAMS", str(self._default_pad_streams()))))]
         self.copy_stream = new_stream(device)
         self._capture()
         if after_capture is not None:
@@ -325,6 +325,9 @@ class _GraphedStep:
 
     def _n_frozen_parts(self) -> int:
         return 1
+
+    def _default_pad_streams(self) -> int:
+        return 3
 
     def _replay(self):
         """refresh_lrs + the graph(s) of one step on the current stream."""
@@ -547,6 +550,11 @@ class GraphedStudentStep(_GraphedStep):
             self._setup(optimizer, device, world, group, split, pipeline_teacher, warmup, before_capture, after_capture)
         finally:
             lib().medp_gemm_persistent_cap(prev)
+
+    def _default_pad_streams(self) -> int:
+        # three branches instead of two move the bad hardware-queue phase: with the roles swapped it is 3 pad streams (the staged pixel copy
+        # then costs 0.26-0.4 ms per step: 8.58 k PCIe-inclusive against 9.54-9.57 k at 0 / 1 / 2, profiles/r03_ab_experiments.txt)
+        return 1 if self.swap_roles else 3
 
     def _teacher_logit(self, bufs, forked: bool = False):
         B = bufs["x_ts"].shape[0]

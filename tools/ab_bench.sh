@@ -10,6 +10,6 @@ for r in $(seq 1 $R); do
     out=$(env $e timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-hbm-table "$@" 2>/dev/null | tail -1)
     python3 -c "
 import json,sys
-d=json.loads(sys.argv[1]); print('%-60s %9.1f samples/s %7.3f ms  resident %s  gemm %s TF' % (sys.argv[2], d['value'], d['ms_per_step'], d['config'].get('resident_batch_samples_per_s'), d['roofline'].get('achieved')))" "$out" "$e"
+d=json.loads(sys.argv[1]); print('%-60s %9.1f samples/s %7.3f ms  PCIe-incl %s  phase %s  gemm %s TF' % (sys.argv[2], d['value'], d['ms_per_step'], d['config'].get('pcie_inclusive_samples_per_s'), d['config'].get('hw_queue_phase'), d['roofline'].get('achieved')))" "$out" "$e"
   done
 done
