@@ -138,6 +138,10 @@ int medp_scalenorm_fwd(const float* x, int ldx, const float* g, void* y, int ldy
                        float eps, void* stream);
 int medp_scalenorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* g, const float* rnorm, float* dx,
                        int lddx, int accumulate_dx, float* dg, float* workspace_rows, int rows, int D, void* stream);
+/* dx = add + d ScaleNorm(x) / dx applied to dy: the residual join of a pre-norm block (x feeds the norm AND the residual) in the backward,
+ * out of place — `add` (the gradient that arrived through the residual) is only read.  dg as above. */
+int medp_scalenorm_bwd_add(const float* dy, int lddy, const float* x, int ldx, const float* g, const float* rnorm, const float* add,
+                           int ldadd, float* dx, int lddx, float* dg, float* workspace_rows, int rows, int D, void* stream);
 
 /* ---- layout / pointwise ------------------------------------------------------------------------------ */
 int medp_cast_f32_bf16(const float* x, int ldx, void* y, int ldy, int rows, int cols, void* stream);

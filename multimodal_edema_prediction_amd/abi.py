@@ -86,6 +86,7 @@ SIGNATURES = {
     "medp_colsum_f32": (I, [P, I, P, P, I, I, P]),
     "medp_scalenorm_fwd": (I, [P, I, P, P, I, I, P, I, I, F, P]),
     "medp_scalenorm_bwd": (I, [P, I, P, I, P, P, P, I, I, P, P, I, I, P]),
+    "medp_scalenorm_bwd_add": (I, [P, I, P, I, P, P, P, I, P, I, P, P, I, I, P]),
     "medp_cast_f32_bf16": (I, [P, I, P, I, I, I, P]),
     "medp_transpose_to_bf16": (I, [P, I, I, P, I, I, I, P]),
     "medp_weight_operands_multi": (I, [P, P, P, I, P]),

@@ -266,35 +266,40 @@ __global__ __launch_bounds__(256) void scalenorm_fwd_reg_kernel(const float* __r
     }
 }
 
-// dx = s*rn*(dy - x*rn^2*<dy,x>),  s = sqrt(D)*g ;  dg_row = sqrt(D)*rn*<dy,x>   (summed over rows by the caller)
+// dx = [acc_src +] s*rn*(dy - x*rn^2*<dy,x>),  s = sqrt(D)*g ;  dg_row = sqrt(D)*rn*<dy,x>   (summed over rows by sum_all_kernel).
+// acc_src may alias dx (the in-place accumulate form) or be a third tensor: dx = acc_src + ..., the residual join of a pre-norm block
+// without touching the incoming gradient.  (Measured and rejected: the LAST workgroup finishing the dg sum behind a ticket — the
+// agent-scope fence every workgroup then needs writes back L2 1500 times per launch: student step 7.36 ms against 6.71,
+// profiles/r03_ab_experiments.txt section 12.)
 __global__ __launch_bounds__(256) void scalenorm_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
-                                                            const float* __restrict__ g, const float* __restrict__ rnorm,
-                                                            float* __restrict__ dx, int lddx, float* __restrict__ dg_rows, int rows,
-                                                            int D, int accumulate) {
+                                                            const float* __restrict__ g, const float* __restrict__ rnorm, const float* acc_src,
+                                                            int ldacc, float* dx, int lddx, float* dg_rows, int rows, int D) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float* xr = x + (size_t)row * ldx;
-    const float* gr = dy + (size_t)row * lddy;
-    const int D4 = D >> 2;
-    float dot = 0.f;
-    for (int i = lane; i < D4; i += 64) {
-        const float4 v = *(const float4*)(xr + 4 * i), d = *(const float4*)(gr + 4 * i);
-        dot += (v.x * d.x + v.y * d.y) + (v.z * d.z + v.w * d.w);
-    }
-    dot = wave_sum(dot);
-    const float rn = rnorm[row], sq = sqrtf((float)D);
-    if (lane == 0 && dg_rows) dg_rows[row] = sq * rn * dot;
-    const float s = sq * g[0] * rn, k = rn * rn * dot;
-    float* dr = dx + (size_t)row * lddx;
-    for (int i = lane; i < D4; i += 64) {
-        const float4 v = *(const float4*)(xr + 4 * i), d = *(const float4*)(gr + 4 * i);
-        float4 o = make_float4(s * (d.x - v.x * k), s * (d.y - v.y * k), s * (d.z - v.z * k), s * (d.w - v.w * k));
-        if (accumulate) {
-            const float4 old = *(const float4*)(dr + 4 * i);
-            o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+    {
+        const float* xr = x + (size_t)row * ldx;
+        const float* gr = dy + (size_t)row * lddy;
+        const int D4 = D >> 2;
+        float dot = 0.f;
+        for (int i = lane; i < D4; i += 64) {
+            const float4 v = *(const float4*)(xr + 4 * i), d = *(const float4*)(gr + 4 * i);
+            dot += (v.x * d.x + v.y * d.y) + (v.z * d.z + v.w * d.w);
         }
-        *(float4*)(dr + 4 * i) = o;
+        dot = wave_sum(dot);
+        const float rn = rnorm[row], sq = sqrtf((float)D);
+        if (lane == 0 && dg_rows) dg_rows[row] = sq * rn * dot;
+        const float s = sq * g[0] * rn, k = rn * rn * dot;
+        float* dr = dx + (size_t)row * lddx;
+        for (int i = lane; i < D4; i += 64) {
+            const float4 v = *(const float4*)(xr + 4 * i), d = *(const float4*)(gr + 4 * i);
+            float4 o = make_float4(s * (d.x - v.x * k), s * (d.y - v.y * k), s * (d.z - v.z * k), s * (d.w - v.w * k));
+            if (acc_src) {
+                const float4 old = *(const float4*)(acc_src + (size_t)row * ldacc + 4 * i);
+                o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+            }
+            *(float4*)(dr + 4 * i) = o;
+        }
     }
 }
 
@@ -303,40 +308,42 @@ __global__ __launch_bounds__(256) void scalenorm_bwd_kernel(const float* __restr
 template <int NV>
 __global__ __launch_bounds__(256) void scalenorm_bwd_reg_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
                                                                 const float* __restrict__ g, const float* __restrict__ rnorm,
-                                                                float* __restrict__ dx, int lddx, float* __restrict__ dg_rows, int rows,
-                                                                int D, int accumulate) {
+                                                                const float* acc_src, int ldacc, float* dx, int lddx, float* dg_rows, int rows,
+                                                                int D) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float* xr = x + (size_t)row * ldx;
-    const float* gr = dy + (size_t)row * lddy;
-    const int D4 = D >> 2;
-    float4 v[NV], d[NV];
-    float dot = 0.f;
+    {
+        const float* xr = x + (size_t)row * ldx;
+        const float* gr = dy + (size_t)row * lddy;
+        const int D4 = D >> 2;
+        float4 v[NV], d[NV];
+        float dot = 0.f;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        const int i = lane + 64 * j;
-        const bool ok = i < D4;
-        v[j] = ok ? *(const float4*)(xr + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
-        d[j] = ok ? *(const float4*)(gr + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+        for (int j = 0; j < NV; ++j) {
+            const int i = lane + 64 * j;
+            const bool ok = i < D4;
+            v[j] = ok ? *(const float4*)(xr + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            d[j] = ok ? *(const float4*)(gr + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
-    for (int j = 0; j < NV; ++j) dot += (v[j].x * d[j].x + v[j].y * d[j].y) + (v[j].z * d[j].z + v[j].w * d[j].w);
-    dot = wave_sum(dot);
-    const float rn = rnorm[row], sq = sqrtf((float)D);
-    if (lane == 0 && dg_rows) dg_rows[row] = sq * rn * dot;
-    const float s = sq * g[0] * rn, k = rn * rn * dot;
-    float* dr = dx + (size_t)row * lddx;
+        for (int j = 0; j < NV; ++j) dot += (v[j].x * d[j].x + v[j].y * d[j].y) + (v[j].z * d[j].z + v[j].w * d[j].w);
+        dot = wave_sum(dot);
+        const float rn = rnorm[row], sq = sqrtf((float)D);
+        if (lane == 0 && dg_rows) dg_rows[row] = sq * rn * dot;
+        const float s = sq * g[0] * rn, k = rn * rn * dot;
+        float* dr = dx + (size_t)row * lddx;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        const int i = lane + 64 * j;
-        if (i < D4) {
-            float4 o = make_float4(s * (d[j].x - v[j].x * k), s * (d[j].y - v[j].y * k), s * (d[j].z - v[j].z * k), s * (d[j].w - v[j].w * k));
-            if (accumulate) {
-                const float4 old = *(const float4*)(dr + 4 * i);
-                o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+        for (int j = 0; j < NV; ++j) {
+            const int i = lane + 64 * j;
+            if (i < D4) {
+                float4 o = make_float4(s * (d[j].x - v[j].x * k), s * (d[j].y - v[j].y * k), s * (d[j].z - v[j].z * k), s * (d[j].w - v[j].w * k));
+                if (acc_src) {
+                    const float4 old = *(const float4*)(acc_src + (size_t)row * ldacc + 4 * i);
+                    o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+                }
+                *(float4*)(dr + 4 * i) = o;
             }
-            *(float4*)(dr + 4 * i) = o;
         }
     }
 }
@@ -480,21 +487,33 @@ extern "C" int medp_scalenorm_fwd(const float* x, int ldx, const float* g, void*
     return 0;
 }
 
-extern "C" int medp_scalenorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* g, const float* rnorm, float* dx,
-                                  int lddx, int accumulate_dx, float* dg, float* workspace_rows, int rows, int D, void* stream) {
+static int scalenorm_bwd_launch(const float* dy, int lddy, const float* x, int ldx, const float* g, const float* rnorm, const float* acc_src,
+                                int ldacc, float* dx, int lddx, float* dg, float* workspace_rows, int rows, int D, void* stream) {
     MEDP_CHECK_ARG(dy && x && g && rnorm && dx, "scalenorm_bwd: null operand");
-    MEDP_CHECK_ARG(rows > 0 && D % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "scalenorm_bwd: alignment");
+    MEDP_CHECK_ARG(rows > 0 && D % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ldacc % 4 == 0, "scalenorm_bwd: alignment");
     MEDP_CHECK_ARG(!dg || workspace_rows, "scalenorm_bwd: dg needs a rows-float workspace");
     hipStream_t s = (hipStream_t)stream;
     const int nv = (D / 4 + 63) / 64;
     float* dgr = dg ? workspace_rows : nullptr;
-    if (nv <= 5) scalenorm_bwd_reg_kernel<5><<<(rows + 3) / 4, 256, 0, s>>>(dy, lddy, x, ldx, g, rnorm, dx, lddx, dgr, rows, D, accumulate_dx);
-    else if (nv <= 10) scalenorm_bwd_reg_kernel<10><<<(rows + 3) / 4, 256, 0, s>>>(dy, lddy, x, ldx, g, rnorm, dx, lddx, dgr, rows, D, accumulate_dx);
-    else scalenorm_bwd_kernel<<<(rows + 3) / 4, 256, 0, s>>>(dy, lddy, x, ldx, g, rnorm, dx, lddx, dgr, rows, D, accumulate_dx);
+    const int grid = (rows + 3) / 4;
+    if (nv <= 5) scalenorm_bwd_reg_kernel<5><<<grid, 256, 0, s>>>(dy, lddy, x, ldx, g, rnorm, acc_src, ldacc, dx, lddx, dgr, rows, D);
+    else if (nv <= 10) scalenorm_bwd_reg_kernel<10><<<grid, 256, 0, s>>>(dy, lddy, x, ldx, g, rnorm, acc_src, ldacc, dx, lddx, dgr, rows, D);
+    else scalenorm_bwd_kernel<<<grid, 256, 0, s>>>(dy, lddy, x, ldx, g, rnorm, acc_src, ldacc, dx, lddx, dgr, rows, D);
     MEDP_LAUNCH_CHECK("medp_scalenorm_bwd");
     if (dg) {
         sum_all_kernel<<<1, 256, 0, s>>>(workspace_rows, dg, rows);
         MEDP_LAUNCH_CHECK("medp_scalenorm_bwd(dg)");
     }
     return 0;
+}
+
+extern "C" int medp_scalenorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* g, const float* rnorm, float* dx,
+                                  int lddx, int accumulate_dx, float* dg, float* workspace_rows, int rows, int D, void* stream) {
+    return scalenorm_bwd_launch(dy, lddy, x, ldx, g, rnorm, accumulate_dx ? dx : nullptr, lddx, dx, lddx, dg, workspace_rows, rows, D, stream);
+}
+
+extern "C" int medp_scalenorm_bwd_add(const float* dy, int lddy, const float* x, int ldx, const float* g, const float* rnorm, const float* add,
+                                      int ldadd, float* dx, int lddx, float* dg, float* workspace_rows, int rows, int D, void* stream) {
+    MEDP_CHECK_ARG(add, "scalenorm_bwd_add: null operand");
+    return scalenorm_bwd_launch(dy, lddy, x, ldx, g, rnorm, add, ldadd, dx, lddx, dg, workspace_rows, rows, D, stream);
 }

@@ -274,9 +274,8 @@ class ResidualScaleNormFn(torch.autograd.Function):
     """(x, ScaleNorm(x)) with the residual join folded into the backward: an encoder's x feeds BOTH the residual of the next Linear and
     the ScaleNorm in front of it, so autograd used to sum the two gradient branches with a torch `add` (12 launches of an 88-MB pass per
     student step, profiles/r02_kerneltrace_bench_student.txt).  Here the residual branch's gradient arrives as the gradient of the first
-    output and `medp_scalenorm_bwd` ACCUMULATES the norm branch into it (accumulate_dx = 1): one pass less per join, no torch kernel.
-    The incoming tensor is updated in place: in this chain it is the `dy` a Linear's backward hands through to its residual input,
-    produced by the ScaleNorm backward one block up and referenced by nobody else."""
+    output and `medp_scalenorm_bwd_add` writes  d_pass + (norm branch)  in the same pass that computes the norm branch: one pass less per
+    join, no torch kernel, and the incoming gradient is only read."""
 
     @staticmethod
     def forward(ctx, x, g, eps):
@@ -290,16 +289,12 @@ class ResidualScaleNormFn(torch.autograd.Function):
         x, g, rn = ctx.saved_tensors
         if dy is None:
             return d_pass, None, None
-        if d_pass is None or not d_pass.is_contiguous() or d_pass.dtype != F32:
+        if d_pass is None or d_pass.dtype != F32:
             dx, dg = Fn.scalenorm_bwd(dy.contiguous(), x, g, rn, need_dg=True)
             return (dx if d_pass is None else dx + d_pass), dg, None
-        dy2, x2 = dy.contiguous().view(-1, x.shape[-1]), x.view(-1, x.shape[-1])
-        rows, D = x2.shape
-        dg = torch.empty(1, dtype=F32, device=x.device)
-        ws = torch.empty(rows, dtype=F32, device=x.device)
-        check(lib().medp_scalenorm_bwd(ptr(dy2), D, ptr(x2), D, ptr(g), ptr(rn), ptr(d_pass), D, 1, ptr(dg), ptr(ws), rows, D, stream()),
-              "scalenorm_bwd(accumulate)")
-        return d_pass, dg, None
+        D = x.shape[-1]
+        dx, dg = _scalenorm_bwd_join(dy.contiguous().view(-1, D), x, g, rn, d_pass.contiguous().view(-1, D))
+        return dx.view_as(x), dg, None
 
 
 _FOLD_RESIDUAL_ADD = __import__("os").environ.get("MEDP_DUETT_FOLD_RESIDUAL_ADD", "1") == "1"
@@ -357,23 +352,25 @@ class SelfAttnQKVFn(torch.autograd.Function):
 _FUSED_NODES = __import__("os").environ.get("MEDP_DUETT_FUSED_NODES", "1") == "1"
 
 
-def _scalenorm_bwd_into(dh, x, g, rn, d_pass):
-    """d_pass += d ScaleNorm(x) / dx applied to dh (in place: `d_pass` is the gradient of the half's output, which the residual hands
-    straight through); returns dg [1]."""
+def _scalenorm_bwd_join(dh, x, g, rn, d_pass):
+    """(d_pass + d ScaleNorm(x) / dx applied to dh, dg [1]): the residual join of a pre-norm half in the backward as ONE pass, out of place —
+    `d_pass` (the gradient of the half's output, which the residual hands straight through) is only read."""
     x2 = x.view(-1, x.shape[-1])
     rows, D = x2.shape
+    dx = torch.empty((rows, D), dtype=F32, device=x.device)
     dg = torch.empty(1, dtype=F32, device=x.device)
     ws = torch.empty(rows, dtype=F32, device=x.device)
-    check(lib().medp_scalenorm_bwd(ptr(dh), D, ptr(x2), D, ptr(g), ptr(rn), ptr(d_pass), D, 1, ptr(dg), ptr(ws), rows, D, stream()),
-          "scalenorm_bwd(accumulate)")
-    return dg
+    check(lib().medp_scalenorm_bwd_add(ptr(dh), D, ptr(x2), D, ptr(g), ptr(rn), ptr(d_pass), D, ptr(dx), D, ptr(dg), ptr(ws), rows, D, stream()),
+          "scalenorm_bwd_add")
+    return dx, dg
 
 
 class AttnHalfFn(torch.autograd.Function):
     """x + to_out(Attention(ScaleNorm(x)))  — the attention half of an x_transformers pre-norm block (duett/duett.py:95-105) as ONE autograd
     node with 16-bit hand-overs inside: ScaleNorm writes the qkv GEMM's bf16 operand, that GEMM writes bf16 q | k | v, the MFMA attention
     (csrc/attention_dh16_train.hip, io_bf16 = 1) reads them and writes bf16 o, the out-projection adds the residual in its epilogue.
-    Backward: one cast of dY, then dO, dQ | dK | dV in bf16 between the kernels, and the ScaleNorm backward accumulated into dY.
+    Backward: one cast of dY, then dO, dQ | dK | dV in bf16 between the kernels, and the ScaleNorm backward joined with dY (the residual's
+    gradient) in one out-of-place pass.
     Every value is rounded to bf16 exactly where the separate nodes (ScaleNormFn -> LinearFn -> SelfAttnQKVFn -> LinearFn) round it, so
     the results are bit-identical; 13 cast / transpose / concatenation launches per block and step fewer."""
 
@@ -413,8 +410,8 @@ class AttnHalfFn(torch.autograd.Function):
                                              dh, dh ** -0.5, p, seed, sid, stream()), "attn_dh16_train_bwd(bf16)")
         dhid = Fn.gemm(dqkv16, A.weights_cat_t_bf16(ws), out_dtype=F32, k=3 * Dv)                     # [B*N, D]
         dwq, dwk, dwv = Fn.gemm_tn(dqkv16, h16.view(B * N, D)).split([w.shape[0] for w in ws], 0)
-        dg = _scalenorm_bwd_into(dhid, xc, g, rn, dy2)
-        return dy2.view(B, N, D), dg, None, dwq, dwk, dwv, dwo, None, None, None, None
+        dx, dg = _scalenorm_bwd_join(dhid, xc, g, rn, dy2)
+        return dx.view(B, N, D), dg, None, dwq, dwk, dwv, dwo, None, None, None, None
 
 
 class FeedForwardHalfFn(torch.autograd.Function):
@@ -451,8 +448,8 @@ class FeedForwardHalfFn(torch.autograd.Function):
         dhid = Fn.gemm(df16, A.weight_t_bf16(w1), out_dtype=F32, k=w1.shape[0])                       # [B*N, D]
         dw1 = Fn.gemm_tn(df16, h16.view(B * N, D))
         db1 = Fn.colsum(df)
-        dg = _scalenorm_bwd_into(dhid, xc, g, rn, dy2)
-        return dy2.view(B, N, D), dg, None, dw1, db1, dw2, db2, None, None, None
+        dx, dg = _scalenorm_bwd_join(dhid, xc, g, rn, dy2)
+        return dx.view(B, N, D), dg, None, dw1, db1, dw2, db2, None, None, None
 
 
 def _fused_nodes_ok(m, x):

@@ -138,6 +138,15 @@ def test_scalenorm_fwd_bwd(rows, D):
     dx, dg = Fn.scalenorm_bwd(dy.to(DEV), x.to(DEV), g.to(DEV), rn)
     assert_close(dx, xr.grad, 1e-4, 1e-5, "scalenorm dx")
     assert_close(dg, gr.grad, 1e-4, 1e-3, "scalenorm dg")
+    # the residual join, out of place: dx = add + (norm branch); `add` untouched
+    from multimodal_edema_prediction_amd.abi import check, lib, ptr, stream
+    add = rnd(rows, D, seed=3).to(DEV)
+    add0 = add.clone()
+    xd, dyd, gd = x.to(DEV), dy.to(DEV), g.to(DEV)
+    dx2, dg2, ws = torch.empty_like(xd), torch.empty(1, device=DEV), torch.empty(rows, device=DEV)
+    check(lib().medp_scalenorm_bwd_add(ptr(dyd), D, ptr(xd), D, ptr(gd), ptr(rn), ptr(add), D, ptr(dx2), D, ptr(dg2), ptr(ws), rows, D, stream()), "bwd_add")
+    assert torch.equal(add, add0)
+    assert torch.equal(dx2, dx + add0) and torch.equal(dg2, dg)
 
 
 def test_colsum_and_cast_transpose():
