@@ -2,6 +2,8 @@
 // fragment reads issued inside its own MFMA stream.  4 waves per workgroup, one workgroup per CU; every iteration is 64 independent
 // v_mfma_f32_16x16x32_bf16 (a 128 x 128 wave tile's K-step) with `pieces` global_load_lds (16 B per lane) and `reads` ds_read_b128
 // spread between them.  Output: wall-clock ticks (100 MHz) of the loop per workgroup.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -53,9 +55,9 @@ __global__ __launch_bounds__(256) void mfma_dma_probe_kernel(const char* __restr
 }
 
 template <int P, int R>
-int run(const char* src, size_t bytes, int iters, unsigned long long* out, float* sink, hipStream_t s) {
+int run(const char* src, size_t bytes, int iters, unsigned long long* out, float* sink, hipStream_t s, int grid) {
     (void)hipFuncSetAttribute((const void*)mfma_dma_probe_kernel<P, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    mfma_dma_probe_kernel<P, R><<<256, 256, 131072, s>>>(src, bytes, iters, out, sink);
+    mfma_dma_probe_kernel<P, R><<<grid, 256, 131072, s>>>(src, bytes, iters, out, sink);
     return (int)hipGetLastError();
 }
 }  // namespace
@@ -64,7 +66,8 @@ extern "C" int medp_dbg_mfma_dma_probe(int pieces, int reads, const void* src, s
                                        void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const char* p = (const char*)src;
-#define CASE(P, R) if (pieces == P && reads == R) return run<P, R>(p, src_bytes, iters, out, sink, s)
+    static const int grid = [] { const char* e = getenv("MEDP_PROBE_GRID"); return e ? atoi(e) : 256; }();
+#define CASE(P, R) if (pieces == P && reads == R) return run<P, R>(p, src_bytes, iters, out, sink, s, grid)
     CASE(0, 0); CASE(8, 0); CASE(16, 0); CASE(0, 16); CASE(8, 16); CASE(16, 16); CASE(4, 16); CASE(16, 8);
 #undef CASE
     return -1;

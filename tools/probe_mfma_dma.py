@@ -17,6 +17,6 @@ for pieces, reads in ((0, 0), (0, 16), (4, 16), (8, 0), (8, 16), (16, 0), (16, 8
         rc = L.medp_dbg_mfma_dma_probe(pieces, reads, src.data_ptr(), src.numel() * 4, iters, out.data_ptr(), sink.data_ptr(), torch.cuda.current_stream().cuda_stream)
         assert rc == 0, rc
         torch.cuda.synchronize()
-    ticks = out.double().mean().item()                     # 100-MHz ticks for the loop
+    ticks = out[:int(os.environ.get('MEDP_PROBE_GRID', '256'))].double().mean().item()                     # 100-MHz ticks for the loop
     us_per_iter = ticks / 100.0 / iters
     print(f"pieces {pieces:2d} reads {reads:2d}: {us_per_iter * 1e3:7.1f} ns per iteration of 64 MFMAs  (ideal 1024 cycles = {1024 / 2.4:.0f} ns at 2.4 GHz)", flush=True)
