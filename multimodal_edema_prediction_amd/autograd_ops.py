@@ -418,7 +418,11 @@ class LayerNormFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
-def layer_norm(x, w, b, eps=1e-5):
+def layer_norm(x, w, b, eps=1e-5, lowp=False):
+    """`lowp`: the result only feeds Linears — outside autograd (a frozen module's forward) the kernel then writes their bf16 operand
+    directly (same rounding as the cast it replaces); with autograd recording, or in fp32 kernel mode, the fp32 result as ever."""
+    if lowp and not torch.is_grad_enabled() and Fn.precision() != "fp32":
+        return Fn.layernorm(x.contiguous(), w, b, eps, out_dtype=BF16)
     return LayerNormFn.apply(x, w, b, eps)
 
 
@@ -443,7 +447,12 @@ class GeluDropoutFn(torch.autograd.Function):
         return dx, None, None, None
 
 
-def gelu_dropout(x, p=0.0, seed=0, sid=0):
+def gelu_dropout(x, p=0.0, seed=0, sid=0, lowp=False):
+    if lowp and not torch.is_grad_enabled() and Fn.precision() != "fp32":            # see layer_norm
+        xc = x.contiguous()
+        y = torch.empty(xc.shape, dtype=BF16, device=x.device)
+        check(lib().medp_gelu_dropout_fwd_bf16(ptr(xc), ptr(y), xc.numel(), float(p), int(seed), int(sid), stream()), "gelu_dropout_fwd_bf16")
+        return y
     return GeluDropoutFn.apply(x, float(p), int(seed), int(sid))
 
 

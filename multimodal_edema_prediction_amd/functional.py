@@ -56,7 +56,9 @@ def _ld(t: torch.Tensor) -> int:
 
 def operand(x: torch.Tensor) -> torch.Tensor:
     """An activation / gradient as a GEMM operand of the op-level paths: bf16 (HIP cast kernel); in fp32 mode the tensor itself."""
-    return x.contiguous() if _PRECISION == "fp32" else to_bf16(x)
+    if _PRECISION == "fp32":
+        return x.contiguous()
+    return x.contiguous() if x.dtype == BF16 else to_bf16(x)          # already an operand (a producer wrote bf16 directly)
 
 
 def operand_t(x: torch.Tensor) -> torch.Tensor:

@@ -96,14 +96,14 @@ class _PerceiverBlock(nn.Module):
         seed = (A.next_seed() if _seed is None else _seed) if (p_attn > 0 or p_ff > 0 or p_ff2 > 0) else 0
         W, b = self.attn.in_proj_weight, self.attn.in_proj_bias
         q_src = _shared_q if _shared_q is not None else latents
-        qn = A.layer_norm(q_src, self.norm_q.weight, self.norm_q.bias, self.norm_q.eps)
-        kn = A.layer_norm(kv, self.norm_kv.weight, self.norm_kv.bias, self.norm_kv.eps)
+        qn = A.layer_norm(q_src, self.norm_q.weight, self.norm_q.bias, self.norm_q.eps, lowp=True)      # only the projections read these
+        kn = A.layer_norm(kv, self.norm_kv.weight, self.norm_kv.bias, self.norm_kv.eps, lowp=True)
         Q, KV = A.in_proj(qn, kn, W, b, d)
         o, attn_w = A.attn_small(Q, KV, H, (d // H) ** -0.5, p_attn, seed, self._sid, _kv_skip, return_attn)
         latents = A.linear(o, self.attn.out_proj.weight, self.attn.out_proj.bias, residual=latents)
-        h = A.layer_norm(latents, self.norm_ff.weight, self.norm_ff.bias, self.norm_ff.eps)
+        h = A.layer_norm(latents, self.norm_ff.weight, self.norm_ff.bias, self.norm_ff.eps, lowp=True)
         h = A.linear(h, self.ff[0].weight, self.ff[0].bias)
-        h = A.gelu_dropout(h, p_ff, seed, self._sid + 1)
+        h = A.gelu_dropout(h, p_ff, seed, self._sid + 1, lowp=True)
         if p_ff2 > 0:
             y = A.linear(h, self.ff[3].weight, self.ff[3].bias)
             latents = A.dropout_add(y, latents, p_ff2, seed, self._sid + 2)
