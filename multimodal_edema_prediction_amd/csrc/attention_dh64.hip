@@ -183,10 +183,10 @@ __device__ __forceinline__ void key_block(WaveState<NQW>& w, const char* sK, con
 
 // Everything one wave does, specialised on its subtile count: the four waves of a workgroup may run different
 // instantiations (a wave-uniform switch in the kernel), but each executes the same sequence of workgroup barriers.
-template <int NQW>
+template <int NQW, int NT = 256, bool DEFER = false>
 __device__ __forceinline__ void wave_body(const AttnParams& p, char* sK, char* sV, int q0, int b, int h, int tid, int wave) {
     const int lane = tid & 63, fr = lane & 15, kq = lane >> 4;
-    const int niter = p.crows >> 5;
+    const int niter = (p.crows * 8 + NT - 1) / NT;              // 16-B pieces per thread and operand: crows rows x 8 chunks
     const bf16_t* zero = (const bf16_t*)g_zero16_attn;
     const size_t row0 = (size_t)b * p.S;
 
@@ -213,19 +213,20 @@ __device__ __forceinline__ void wave_body(const AttnParams& p, char* sK, char* s
         if (c0 > 0) __syncthreads();   // previous chunk fully consumed
         // ---- stage K, V chunk (LDS-DMA, swizzle on the source chunk index) -----------------
         for (int i = 0; i < niter; ++i) {
-            const int qd = i * 256 + tid;
+            const int qd = i * NT + tid;
             const int row = qd >> 3, c = (qd & 7) ^ (row & 7);
+            if (NT > 256 && row >= p.crows) break;                // (wave-uniform: a wave's 64 pieces are 8 whole rows, crows % 32 == 0)
             const bool ok = row < nkeys;
             const size_t grow = row0 + c0 + row;
-            glds16(ok ? p.k + grow * p.ldk + h * 64 + c * 8 : zero, sK + (i * 256 + wave * 64) * 16);
-            glds16(ok ? p.v + grow * p.ldv + h * 64 + c * 8 : zero, sV + (i * 256 + wave * 64) * 16);
+            glds16(ok ? p.k + grow * p.ldk + h * 64 + c * 8 : zero, sK + (i * NT + wave * 64) * 16);
+            glds16(ok ? p.v + grow * p.ldv + h * 64 + c * 8 : zero, sV + (i * NT + wave * 64) * 16);
         }
         MEDP_WAIT_LDS_DMA();           // the chunk's LDS-DMA has landed ...
         __syncthreads();               // ... before any wave reads it
         if constexpr (NQW > 0) {
             const int nfull = nkeys >> 6;
-            for (int kb = 0; kb < nfull; ++kb) key_block<NQW, false>(w, sK, sV, kb, 64, p.scale_log2e, fr, kq);
-            if (nkeys & 63) key_block<NQW, true>(w, sK, sV, nfull, nkeys & 63, p.scale_log2e, fr, kq);
+            for (int kb = 0; kb < nfull; ++kb) key_block<NQW, false, DEFER>(w, sK, sV, kb, 64, p.scale_log2e, fr, kq);
+            if (nkeys & 63) key_block<NQW, true, DEFER>(w, sK, sV, nfull, nkeys & 63, p.scale_log2e, fr, kq);
         }
     }
 
@@ -267,6 +268,29 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dh64_kernel(const AttnParams 
     else if (nq == 2) wave_body<2>(p, sK, sV, q0, b, h, tid, wave);
     else if (nq == 1) wave_body<1>(p, sK, sV, q0, b, h, tid, wave);
     else wave_body<0>(p, sK, sV, q0, b, h, tid, wave);          // idle wave: staging share and barriers only
+}
+
+// Long sequences (S >= 512: 512 x 512 images give 1370 tokens): the same body in 512-thread workgroups, at most two subtiles per wave.
+// The 4-wave kernel cuts a (b, h) of 86 subtiles into 10 workgroups that EACH stage all of K / V (350 KB) for 8.6 subtiles, and leaves a
+// CU 8 waves to hide the softmax chains behind; here 6 workgroups of 8 waves stage it for 14.3 subtiles each and a CU holds 16 waves
+// (capped at 128 VGPRs: 10 spilled registers cost less than the second workgroup per CU gains — 268.8 us against 325.1 uncapped at
+// B 32, S 1370, H 12; the 4-wave kernel: 292.5; S 1025: 174.5 / 208.7; S 577: 75.9 / 82.4).
+__device__ __forceinline__ void w8_body(const AttnParams& p);
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd_dh64_w8_kernel(const AttnParams p) { w8_body(p); }
+__device__ __forceinline__ void w8_body(const AttnParams& p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;
+    char* sV = smem + p.crows * 128;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int ntile = (p.S + 15) >> 4, nwave = gridDim.x * 8, gw = blockIdx.x * 8 + wave;
+    const int tbase = ntile / nwave, trem = ntile % nwave;
+    const int nq = tbase + (gw < trem ? 1 : 0);                 // subtiles of this wave (wave-uniform, <= 2)
+    const int q0 = (gw * tbase + min(gw, trem)) * 16;
+    if (nq == 2) wave_body<2, 512, true>(p, sK, sV, q0, b, h, tid, wave);
+    else if (nq == 1) wave_body<1, 512, true>(p, sK, sV, q0, b, h, tid, wave);
+    else wave_body<0, 512, true>(p, sK, sV, q0, b, h, tid, wave);
 }
 
 // ---- S = 257 (ViT-B/14 at 224 x 224: the class token + 256 patches): one 512-thread workgroup per (batch, head) ----------------------
@@ -525,8 +549,18 @@ static int attn_fwd_launch(const void* q, const void* k, const void* v, void* o,
     MEDP_ONCE_PER_DEVICE({
         hipFuncSetAttribute((const void*)attn_fwd_dh64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
     });
-    // floor(ntile/8) workgroups: every wave gets 1..3 subtiles (ntile < 8*(nb+1) <= 12*nb)
     const int ntile = (S + 15) / 16;
+    static const int w8_min_s = [] { const char* e = getenv("MEDP_ATTN_W8_MIN_S"); return e ? atoi(e) : 512; }();      // 0 / huge: never (A/B runs)
+    if (w8_min_s > 0 && S >= w8_min_s) {
+        MEDP_ONCE_PER_DEVICE({
+            hipFuncSetAttribute((const void*)attn_fwd_dh64_w8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+        });
+        dim3 grid8((ntile + 15) / 16, H, B);                   // ceil: every wave gets 1..2 subtiles (or none in the last workgroup)
+        attn_fwd_dh64_w8_kernel<<<grid8, 512, LDS, (hipStream_t)stream>>>(p);
+        MEDP_LAUNCH_CHECK("medp_attn_fwd_dh64(8 waves)");
+        return 0;
+    }
+    // floor(ntile/8) workgroups: every wave gets 1..3 subtiles (ntile < 8*(nb+1) <= 12*nb)
     dim3 grid(ntile >= 8 ? ntile / 8 : 1, H, B);
     attn_fwd_dh64_kernel<<<grid, 256, LDS, (hipStream_t)stream>>>(p);
     MEDP_LAUNCH_CHECK("medp_attn_fwd_dh64");

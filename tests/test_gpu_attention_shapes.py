@@ -1,5 +1,5 @@
 """CXR-encoder attention (head dim 64) over the sequence lengths that exercise every wave specialisation of the kernel:
-1 / 2 / 3 query subtiles per wave, idle waves, ragged key tails, and the multi-chunk path (S > 320).  Reference: the same
+1 / 2 / 3 query subtiles per wave, idle waves, ragged key tails, the multi-chunk path (S > 320) and the 8-wave kernel of long sequences (S >= 512).  Reference: the same
 softmax(QK^T/8)V in fp32 torch on the bf16 operands (Dinov2SelfAttention as called from the reference model :152-158)."""
 import pytest
 import torch
@@ -8,7 +8,9 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("B,S,H", [(2, 256, 2), (2, 257, 3), (2, 272, 2), (1, 320, 2), (1, 64, 2), (1, 100, 2), (1, 17, 1),
-                                   (1, 1, 2), (1, 400, 2), (1, 1297, 2)])
+                                   (1, 1, 2), (1, 400, 2), (1, 1297, 2),
+                                   # S >= 512: the 8-wave kernel (<= 2 subtiles per wave; idle waves in the last workgroup; 2 .. 7 key chunks)
+                                   (2, 512, 2), (1, 513, 3), (2, 577, 2), (1, 1024, 2), (2, 1370, 3), (1, 2049, 1)])
 def test_attn_dh64_shapes(B, S, H):
     from multimodal_edema_prediction_amd import functional as Fn
     torch.manual_seed(S)
